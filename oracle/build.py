@@ -1,0 +1,18 @@
+"""Build the C restatement (oracle/_build/libcitation_oracle.so).  Test infrastructure."""
+import os, subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, '_build', 'libcitation_oracle.so')
+
+
+def build(force=False):
+    srcs = [os.path.join(HERE, f) for f in ('citation_ref.c', 'citation_rt.h', 'citation_step.h')]
+    srcs += [os.path.join(HERE, 'gen', f) for f in sorted(os.listdir(os.path.join(HERE, 'gen')))]
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
+        return LIB
+    subprocess.run(['make', '-C', HERE, '-s'], check=True)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force=True))

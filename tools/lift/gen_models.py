@@ -195,6 +195,11 @@ def lift_build(ref, build, prefix):
         'sin@plt': ('LIFT_SIN', [('xmm0', 'f')], 'f'),
         'cos@plt': ('LIFT_COS', [('xmm0', 'f')], 'f'),
         'tan@plt': ('LIFT_TAN', [('xmm0', 'f')], 'f'),
+        'atan@plt': ('LIFT_ATAN', [('xmm0', 'f')], 'f'),
+        'atan2@plt': ('LIFT_ATAN2', [('xmm0', 'f'), ('xmm1', 'f')], 'f'),
+        'asin@plt': ('LIFT_ASIN', [('xmm0', 'f')], 'f'),
+        'acos@plt': ('LIFT_ACOS', [('xmm0', 'f')], 'f'),
+        'log@plt': ('LIFT_LOG', [('xmm0', 'f')], 'f'),
         'floor@plt': ('LIFT_FLOOR', [('xmm0', 'f')], 'f'),
     }
     # lifted leaf functions take the read-only pool first
@@ -202,6 +207,9 @@ def lift_build(ref, build, prefix):
         cn, args, ret = rules['calls'][by[k]]
         rules['calls'][by[k]] = (cn, [('ro', 'ctx')] + args, ret)
 
+    der_ins = funcs[(by['citation_to_python_derivatives'], 'citation_to_python_derivatives')]
+    xdot_off = next(i for i in der_ins if i.ripabs and M <= i.ripabs < M + 0x10000).ripabs - M
+    rules['ptr_loads'][('M', xdot_off)] = ('XDOT', 0)
     L = XL.Lifter(so, funcs, got, ro_lo, ro_sz, rules)
     S = XL.Spec
     pieces = []
@@ -226,6 +234,9 @@ def lift_build(ref, build, prefix):
                                  extra_params=ROP + ', const double *su, double *sy'))
     lift('mdlOutputs', mdl[1], S(P + 'ac_axes', [], 'void', entry={'rdi': ('SIMS', 0)},
                                  extra_params=ROP + ', const double *su, double *sy, int mode'))
+    lift('citation_to_python_derivatives', by['citation_to_python_derivatives'],
+         S(P + 'derivatives', [], 'void', extra_params='CitCtx *c, double *xdot',
+           ret_expr='const double *ro = c->ro; (void)ro;'))
     lift('step', by['step'], S(P + 'model', [], 'void', entry={'rdi': ('CMD', 0), 'rsi': ('OUT', 0)},
                                extra_params='CitCtx *c, const double *cmd, double *out',
                                ret_expr='const double *ro = c->ro;'))
@@ -263,20 +274,47 @@ def lift_build(ref, build, prefix):
     return body, ro, info, meta
 
 
+CODE_NAMES = {'h2000_v90': 'nominal'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
-    ap.add_argument('--outdir', default=None)
     ap.add_argument('builds', nargs='*')
     a = ap.parse_args()
     root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    for b in (a.builds or ['h2000_v90']):
-        body, ro, info, meta = lift_build(a.ref, b, 'cit_%s_' % b)
-        out = a.outdir or os.path.join(root, 'oracle', 'gen')
-        os.makedirs(out, exist_ok=True)
-        open(os.path.join(out, 'citation_%s.inc' % b), 'w').write(body)
-        print(b, 'lifted:', len(body.splitlines()), 'lines; cut @%x -> %x' % (meta['cut'], meta['outcopy']),
-              'dt', meta['dt'])
+    outdirs = [os.path.join(root, 'oracle', 'gen'), os.path.join(root, 'serl_amd', 'csrc', 'gen')]
+    datadir = os.path.join(root, 'serl_amd', 'data')
+    for d in outdirs + [datadir]:
+        os.makedirs(d, exist_ok=True)
+    index = {}
+    by_md5, by_code = {}, {}
+    for b in (a.builds or BUILDS):
+        md5 = hashlib.md5(open(so_path(a.ref, b), 'rb').read()).hexdigest()
+        if md5 in by_md5:
+            index[b] = dict(index[by_md5[md5]])
+            continue
+        by_md5[md5] = b
+        body, ro, info, meta = lift_build(a.ref, b, 'cit_@KEY@_')
+        lines = body.splitlines()
+        h = hashlib.sha1('\n'.join(lines[1:]).encode()).hexdigest()
+        if h not in by_code:
+            key = CODE_NAMES.get(b, b)
+            by_code[h] = key
+            text = body.replace('@KEY@', key)
+            for d in outdirs:
+                open(os.path.join(d, 'citation_%s.inc' % key), 'w').write(text)
+            print('code variant %-10s from envs/%s: %d lines' % (key, b, len(lines)))
+        key = by_code[h]
+        t3e = next(e for e in info['sfun'] if e['kind'] == 'table3')
+        t3 = np.array(sum([p['v'] for p in t3e['P']], []), dtype=np.float64)
+        assert t3.shape == (46,) and [(p['m'], p['n']) for p in t3e['P']] == [(1, 3), (4, 1), (1, 3), (4, 9)]
+        np.savez_compressed(os.path.join(datadir, 'citation_%s.npz' % b), ro=ro, x0=info['x0'], dw0=info['dw0'],
+                            y0=info['y0'], t3=t3, dt=np.float64(meta['dt']), nB=np.int64(meta['nB']),
+                            ro_base=np.int64(meta['ro_base']))
+        index[b] = dict(data=b, code=key, nB=meta['nB'])
+        print('build %-10s -> data %s, code %s' % (b, b, key))
+    json.dump(index, open(os.path.join(datadir, 'builds.json'), 'w'), indent=1, sort_keys=True)
 
 
 if __name__ == '__main__':

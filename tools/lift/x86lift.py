@@ -300,7 +300,11 @@ class Lifter:
                 a = (a[0], a[1] & 0xffffffff)
             setreg(ops[1][1:], a)
             return
-        if mn in ('movslq', 'movzbl', 'movzwl', 'movsbl', 'cltq', 'cvttsd2si', 'cvttss2si', 'cmovg'):
+        if mn.startswith('set') and len(ops) == 1:
+            if self.is_reg(ops[0]):
+                setreg(ops[0][1:], INT)
+            return
+        if mn in ('movslq', 'movzbl', 'movzwl', 'movsbl', 'cltq', 'cvttsd2si', 'cvttss2si') or mn.startswith('cmov'):
             dst = 'rax' if mn == 'cltq' else ops[-1][1:]
             if mn == 'cltq':
                 av = R['rax']
@@ -653,6 +657,14 @@ class Emitter:
             return ['goto L_%x;' % ins.target]
         if mn.startswith('j'):
             return ['if (%s) goto L_%x;' % (self.cond(mn[1:], st, ins), ins.target)]
+        if mn.startswith('set') and len(ops) == 1 and isreg(ops[0]):
+            return [self.reg_write(ops[0][1:], '(%s) ? 1 : 0' % self.cond(mn[3:], st, ins))]
+        if mn in ('movzbl', 'movzwl'):
+            src, dst = ops
+            w = 8 if mn == 'movzbl' else 16
+            if not isreg(src):
+                raise ValueError('movz from memory')
+            return [self.reg_write(dst[1:], '(uint64_t)(uint%d_t)%s' % (w, _SUB[src[1:]][0]))]
         if mn.startswith('cmov'):
             return ['if (%s) { %s }' % (self.cond(mn[4:], st, ins),
                                        self.reg_write(ops[1][1:], self.reg_read(ops[0][1:])))]
