@@ -1,0 +1,149 @@
+/* serl_amd.h -- C ABI of the MI355X-native population-rollout fitness evaluator for SERL.
+ *
+ * Drop-in boundary.  The reference has no FFI for this path: its seam is Python
+ * (`Agent.evaluate`, base/core/agent.py:63-138, driven by the GA loop at :229-256) on top of the
+ * SWIG surface of its native dynamics library,
+ *       void initialize(void);  void step(real_T *cmd, real_T *out);  void ..._terminate(void);
+ * (DWARF citation_to_python.h:1600-1604; envs/h2000_v90/citation.py:65-72).  This library replaces
+ * that whole inner loop -- actor MLP forward (base/core/genetic_agent.py:104-109,
+ * base/core/mod_utils.py:39-50) -> CitationEnv.step (envs/phlabenv.py:430-482) -> native step() ->
+ * reward/cost/bounds (envs/phlabenv.py:347-399) -- with one fused HIP kernel batched over episodes.
+ *
+ * Conventions: every entry point returns 0 on success or a negative SERL_E_* code and never
+ * throws; `serl_last_error()` returns a thread-local message.  All array arguments of
+ * `serl_rollout` / `serl_ga_*` are DEVICE pointers owned by the caller (PyTorch allocates them);
+ * the context owns only the read-only model tables it uploaded.  Calls are asynchronous on the
+ * `hipStream_t` passed as `void *stream` (NULL = default stream); the caller synchronises.
+ * The CPU oracle (oracle/rollout_ref.c, test infrastructure) implements `serl_oracle_rollout` with
+ * the same descriptor and HOST pointers.
+ */
+#ifndef SERL_AMD_H
+#define SERL_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SERL_ABI_VERSION 1
+
+enum serl_error {
+  SERL_OK = 0,
+  SERL_E_INVALID = -1,      /* bad argument / descriptor */
+  SERL_E_HIP = -2,          /* HIP runtime error (message in serl_last_error) */
+  SERL_E_UNSUPPORTED = -3,  /* network shape / build variant not compiled in */
+  SERL_E_NOMEM = -4
+};
+
+/* activation_actor of base/core/mod_utils.py:14-18 ('relu' IS LeakyReLU(0.01) there) */
+enum serl_activation { SERL_ACT_TANH = 0, SERL_ACT_ELU = 1, SERL_ACT_LEAKY_RELU = 2 };
+
+/* code variants of the dynamics library (14 build dirs = 5 code variants) */
+enum serl_dyn_code { SERL_DYN_NOMINAL = 0, SERL_DYN_ICE = 1, SERL_DYN_CG_TIMED = 2, SERL_DYN_GUST = 3,
+                     SERL_DYN_TEST = 4 };
+
+typedef struct serl_ctx serl_ctx;
+
+/* Tables + post-initialize() state image of ONE dynamics build (what the reference's
+ * initialize() @0xb4e0 sets up).  HOST pointers; copied by serl_ctx_load_build. */
+typedef struct serl_build_desc {
+  int32_t code;            /* enum serl_dyn_code */
+  int32_t n_ro;            /* number of f64 in ro[] */
+  uint64_t ro_base;        /* virtual address of ro[0] in the reference binary (.rodata start) */
+  const double *ro;        /* .rodata as f64: rtConstP aero tables, rtConstB, literal pool */
+  const double *t3;        /* table3 S-function parameters P1[3] P2[4] P3[3] P4[36] = 46 */
+  const double *x0;        /* rtX after initialize(): 19 continuous states */
+  const double *dw0;       /* rtDW after initialize(): 31 f64 (IWORK in the last 12 bytes) */
+  double dt;               /* fixed step, 0.01 */
+} serl_build_desc;
+
+/* Per-episode actuator-fault row (envs/{be,jr,sa,se}/citation.py:71-79): what the PLANT sees is
+ *   cmd[0] = clip(cmd[0] * elev_gain, -elev_clip, +elev_clip)
+ *   cmd[1] = clip(cmd[1], -ail_clip, +ail_clip)
+ *   cmd[2] = rudder_jam_on ? rudder_jam : cmd[2]
+ * while the logged action (env.last_u) stays the commanded one.  Nominal row: {1, +inf, +inf, 0, 0}. */
+typedef struct serl_fault_row {
+  double elev_gain, elev_clip, ail_clip, rudder_jam_on, rudder_jam, pad0, pad1, pad2;
+} serl_fault_row;
+
+typedef struct serl_rollout_desc {
+  /* -- actor network (base/core/genetic_agent.py:69-102): Linear(S,H) act, L x [Linear(H,H)
+   *    LayerNorm(H) act], Linear(H,A) tanh.  weights: f32 [n_members][param_count], packed in
+   *    state_dict order: W0[H][S] b0[H]  { Wl[H][H] bl[H] gamma_l[H] beta_l[H] } x L  Wo[A][H] bo[A] */
+  int32_t state_dim, action_dim, hidden, num_layers, activation;
+  int32_t n_members;
+  const float *weights;
+  int64_t weight_stride;            /* in floats, >= param_count */
+  /* -- episodes */
+  int32_t n_episodes;
+  int32_t build_slot;               /* slot given to serl_ctx_load_build */
+  const int32_t *member_of_episode; /* [n_episodes] */
+  const serl_fault_row *faults;     /* [n_episodes] or NULL (nominal) */
+  const double *ref;                /* reference signals, radians, sampled at the accumulated env
+                                       time t_k (envs/phlabenv.py:347-349,473): [.., max_steps, 3] */
+  int64_t ref_stride;               /* doubles between consecutive episodes' tables (0 = shared) */
+  const double *err0;               /* [n_episodes][3] tracking error carried into obs0
+                                       (envs/phlabenv.py:401-428 never clears self.error) or NULL=0 */
+  const double *action_noise;       /* [n_episodes][max_steps][3] pre-drawn clipped Gaussian noise
+                                       (base/core/agent.py:90-93) or NULL */
+  double t_max;                     /* 80 (eval) / 20 (train) seconds */
+  int32_t max_steps;                /* rows in ref / trace buffers; 8001 for t_max = 80 */
+  int32_t lanes_per_wave;           /* 0 = auto; episodes packed per 64-lane wavefront (1..64) */
+  /* -- results (per episode) */
+  double *fitness;                  /* sum of rewards incl. termination penalty */
+  int32_t *length_steps;            /* number of env steps taken */
+  double *length_t;                 /* info['t'] after the final increment */
+  int32_t *cost_steps;              /* number of steps with get_cost() == 1 */
+  /* -- optional traces (NULL = not exported) */
+  double *actions;                  /* env.last_u per step:  [n_episodes][max_steps][3] */
+  double *states;                   /* env.x per step:       [n_episodes][max_steps][12] */
+  double *rewards;                  /* reward per step:      [n_episodes][max_steps] */
+  float *transitions;               /* (obs7,a3,next_obs7,r,done,cost) f32 x20 per step:
+                                       [n_episodes][max_steps][20]  (base/core/agent.py:101-112) */
+} serl_rollout_desc;
+
+int serl_abi_version(void);
+/* number of f32 parameters of an actor: H*S+H + L*(H*H+3H) + A*H+A */
+int serl_param_count(int state_dim, int hidden, int num_layers, int action_dim);
+const char *serl_last_error(void);
+
+int serl_ctx_create(int device, serl_ctx **out);
+int serl_ctx_destroy(serl_ctx *ctx);
+int serl_ctx_load_build(serl_ctx *ctx, int slot, const serl_build_desc *build);
+
+/* One population evaluation: all episodes of the descriptor, one fused kernel launch per call. */
+int serl_rollout(serl_ctx *ctx, const serl_rollout_desc *desc, void *stream);
+
+/* Duration (ms) of the most recent serl_rollout kernel on its stream, measured with HIP events
+ * recorded around the launch; blocks until that kernel has finished. */
+int serl_last_rollout_ms(serl_ctx *ctx, float *ms);
+
+/* ---- SSNE weight-tensor edits (base/core/mod_neuro_evo.py) as elementwise kernels.  `weights` is
+ * the same [n_members][stride] f32 tensor; index lists are DEVICE int32/float arrays generated by
+ * the host from the reference's RNG streams so that selection stays bit-compatible. ------------ */
+/* clone (mod_neuro_evo.py:371-382): weights[dst[i]] = weights[src[i]], i < n */
+int serl_ga_clone(serl_ctx *ctx, float *weights, int64_t stride, int32_t param_count,
+                  const int32_t *src, const int32_t *dst, int32_t n, void *stream);
+/* crossover_inplace (mod_neuro_evo.py:61-93): n row/element swaps between two members:
+ *   ops[i] = {offset, length, dir}: dir 0 copies member b -> a, dir 1 copies a -> b, at
+ *   weights[.. + offset .. offset+length) */
+int serl_ga_crossover(serl_ctx *ctx, float *weights, int64_t stride, int32_t member_a, int32_t member_b,
+                      const int32_t *ops, int32_t n_ops, void *stream);
+/* mutate_inplace (mod_neuro_evo.py:329-369): n sparse edits of one member applied IN ORDER:
+ *   kind 0:  w[idx] += z * (strength * w[idx])   (normal / super mutation: random.gauss(0, strength*w) = z*sigma)
+ *   kind 1:  w[idx]  = z                          (reset: random.gauss(0, 1))
+ * each followed by the reference's hard clamp to +-1e6 (regularize_weight, :57-59,366). */
+int serl_ga_mutate(serl_ctx *ctx, float *weights, int64_t stride, int32_t member,
+                   const int32_t *idx, const int32_t *kind, const float *z, const float *strength,
+                   int32_t n, void *stream);
+/* proximal / safe mutation update (mod_neuro_evo.py:183-223, 254-298):
+ *   theta[i] += delta[i] / scaling[i]   over the flat 2-D-weights genome given as (offset,length)
+ *   segments of the packed parameter row */
+int serl_ga_scaled_perturb(serl_ctx *ctx, float *weights, int64_t stride, int32_t member,
+                           const int32_t *seg_offset, const int32_t *seg_length, int32_t n_seg,
+                           const float *delta, const float *scaling, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SERL_AMD_H */

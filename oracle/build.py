@@ -6,7 +6,8 @@ LIB = os.path.join(HERE, '_build', 'libcitation_oracle.so')
 
 
 def build(force=False):
-    srcs = [os.path.join(HERE, f) for f in ('citation_ref.c', 'citation_rt.h', 'citation_step.h')]
+    srcs = [os.path.join(HERE, f) for f in ('citation_ref.c', 'rollout_ref.c', 'citation_rt.h', 'citation_step.h',
+                                            '../include/serl_amd.h')]
     srcs += [os.path.join(HERE, 'gen', f) for f in sorted(os.listdir(os.path.join(HERE, 'gen')))]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
         return LIB

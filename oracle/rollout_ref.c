@@ -1,0 +1,203 @@
+/* rollout_ref.c -- ORACLE (test infrastructure): CPU restatement of one SERL episode and of the GA
+ * population-evaluate loop, with the same descriptor as the product's serl_rollout() but HOST
+ * pointers.  Never linked into the product.
+ *
+ * Follows, line by line:
+ *   base/core/agent.py:63-138        Agent.evaluate  (episode loop, fitness = sum of rewards)
+ *   base/core/genetic_agent.py:104-109  Actor.select_action (obs f64 -> f32 -> MLP -> f32[3])
+ *   base/core/mod_utils.py:14-18,39-50  activations ('relu' = LeakyReLU 0.01), custom LayerNorm
+ *                                        gamma*(x-mean)/(std_unbiased + 1e-6) + beta
+ *   envs/phlabenv.py:62-73           scale_action: 0.5*(a+1.0) in f32, then f64
+ *   envs/phlabenv.py:347-399         calc_error / get_reward / get_cost / check_bounds
+ *   envs/phlabenv.py:401-482         reset / step
+ *   envs/{be,jr,sa,se}/citation.py:71-79   actuator faults seen by the plant only
+ * Float-32 arithmetic of the actor is sequential (acc = bias; acc += w*x in index order, no FMA);
+ * torch's CPU kernels use a different (BLAS) order -- agreement is to f32 rounding, see
+ * tests/test_actor_parity.py.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+#include "../include/serl_amd.h"
+
+typedef struct CitInstance CitInstance;
+int cit_instance_size(void);
+void cit_reset(CitInstance *I, int code, const double *ro, const double *t3, const double *x0,
+               const double *dw0, double dt);
+int cit_step(CitInstance *I, const double *cmd, double *out);
+
+static float act_f(float v, int act)
+{
+  switch (act) {
+    case SERL_ACT_TANH: return tanhf(v);
+    case SERL_ACT_ELU: return v > 0.0f ? v : expm1f(v);
+    default: return v > 0.0f ? v : 0.01f * v;
+  }
+}
+
+/* Actor forward, f32 (genetic_agent.py:69-109).  hbuf: 2*H scratch floats. */
+static void actor_forward(const serl_rollout_desc *d, const float *w, const float *obs, float *act_out,
+                          float *hbuf)
+{
+  const int S = d->state_dim, H = d->hidden, A = d->action_dim, L = d->num_layers;
+  float *h0 = hbuf, *h1 = hbuf + H;
+  const float *W = w, *b = w + (size_t)H * S;
+  for (int i = 0; i < H; ++i) {
+    float acc = b[i];
+    for (int j = 0; j < S; ++j) acc = acc + W[i * S + j] * obs[j];
+    h0[i] = act_f(acc, d->activation);
+  }
+  w = b + H;
+  for (int l = 0; l < L; ++l) {
+    const float *Wl = w, *bl = w + (size_t)H * H, *g = bl + H, *be = g + H;
+    for (int i = 0; i < H; ++i) {
+      float acc = bl[i];
+      for (int j = 0; j < H; ++j) acc = acc + Wl[i * H + j] * h0[j];
+      h1[i] = acc;
+    }
+    float mean = 0.0f;
+    for (int i = 0; i < H; ++i) mean = mean + h1[i];
+    mean = mean / (float)H;
+    float var = 0.0f;
+    for (int i = 0; i < H; ++i) { float dlt = h1[i] - mean; var = var + dlt * dlt; }
+    float std = sqrtf(var / (float)(H - 1));
+    float den = std + 1e-6f;
+    for (int i = 0; i < H; ++i) h0[i] = act_f(g[i] * (h1[i] - mean) / den + be[i], d->activation);
+    w = be + H;
+  }
+  const float *Wo = w, *bo = w + (size_t)A * H;
+  for (int i = 0; i < A; ++i) {
+    float acc = bo[i];
+    for (int j = 0; j < H; ++j) acc = acc + Wo[i * H + j] * h0[j];
+    act_out[i] = tanhf(acc);
+  }
+}
+
+int serl_param_count(int S, int H, int L, int A) { return H * S + H + L * (H * H + 3 * H) + A * H + A; }
+
+static double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, int e, CitInstance *I, float *hbuf)
+{
+  const double PI = 3.14159265358979323846;
+  const double deg2rad = PI / 180.0, rad2deg = 180.0 / PI;
+  const double bound = 10.0 * deg2rad;                 /* phlabenv.py:208 */
+  const double low = -bound, high = bound;
+  const double max_theta = 60.0 * deg2rad, max_phi = 75.0 * deg2rad;   /* :211-212 */
+  const double scaler[3] = {6.0 / PI * 1.0, 6.0 / PI * 1.0, 6.0 / PI * 4.0};  /* :231 */
+  const double dt = 0.01;                              /* phlabenv.py:81 (class attribute) */
+  const serl_fault_row nominal = {1.0, INFINITY, INFINITY, 0.0, 0.0, 0, 0, 0};
+  const serl_fault_row *f = d->faults ? &d->faults[e] : &nominal;
+  const float *w = d->weights + (size_t)d->member_of_episode[e] * d->weight_stride;
+  const double *ref = d->ref + (size_t)e * d->ref_stride;
+  double cmd[10], x[12], err[3] = {0, 0, 0}, obs[7];
+  float obsf[7], a[3];
+
+  /* reset (phlabenv.py:401-428) */
+  cit_reset(I, bd->code, bd->ro, bd->t3, bd->x0, bd->dw0, bd->dt);
+  memset(cmd, 0, sizeof(cmd));
+  cmd[0] = clipd(cmd[0] * f->elev_gain, -f->elev_clip, f->elev_clip);
+  cmd[1] = clipd(cmd[1], -f->ail_clip, f->ail_clip);
+  if (f->rudder_jam_on != 0.0) cmd[2] = f->rudder_jam;
+  cit_step(I, cmd, x);
+  const double V0 = x[3];
+  double t = 0.0;
+  if (d->err0) for (int i = 0; i < 3; ++i) err[i] = d->err0[(size_t)e * 3 + i];
+  obs[0] = err[0]; obs[1] = err[1]; obs[2] = err[2];
+  obs[3] = x[0]; obs[4] = x[1]; obs[5] = x[2]; obs[6] = x[4];
+
+  double fitness = 0.0;
+  int k = 0, cost_steps = 0, done = 0;
+  while (!done) {
+    if (k >= d->max_steps) return SERL_E_INVALID;     /* reference table too short */
+    for (int i = 0; i < 7; ++i) obsf[i] = (float)obs[i];
+    actor_forward(d, w, obsf, a, hbuf);
+    double u[3];
+    if (d->action_noise) {
+      /* agent.py:90-93: f32 action + f64 noise -> f64, clipped; scale_action then runs in f64 */
+      for (int i = 0; i < 3; ++i) {
+        double an = clipd((double)a[i] + d->action_noise[((size_t)e * d->max_steps + k) * 3 + i], -1.0, 1.0);
+        u[i] = low + 0.5 * (an + 1.0) * (high - low);
+      }
+    } else {
+      for (int i = 0; i < 3; ++i) {
+        float s = 0.5f * (a[i] + 1.0f);               /* phlabenv.py:72-73, f32 part */
+        u[i] = low + (double)s * (high - low);
+      }
+    }
+    memset(cmd, 0, sizeof(cmd));
+    cmd[0] = clipd(u[0] * f->elev_gain, -f->elev_clip, f->elev_clip);
+    cmd[1] = clipd(u[1], -f->ail_clip, f->ail_clip);
+    cmd[2] = (f->rudder_jam_on != 0.0) ? f->rudder_jam : u[2];
+    cit_step(I, cmd, x);
+    /* reward (phlabenv.py:347-367): reference at the pre-increment time */
+    const double *rk = ref + (size_t)k * 3;
+    err[0] = rk[0] - x[7]; err[1] = rk[1] - x[6]; err[2] = rk[2] - x[5];
+    double rsum = 0.0;
+    for (int i = 0; i < 3; ++i) rsum = rsum + fabs(clipd(scaler[i] * err[i], -1.0, 1.0));
+    double reward = -rsum / 3.0;
+    /* cost (phlabenv.py:369-375; degrees compared with 0.75*max_phi in radians -- reference quirk) */
+    int cost = (rad2deg * fabs(x[4]) > 11.0) || (rad2deg * fabs(x[6]) > 0.75 * max_phi) || (x[3] < V0 / 3.0);
+    double nobs[7] = {err[0], err[1], err[2], x[0], x[1], x[2], x[4]};
+    /* bounds (phlabenv.py:391-399) */
+    done = (t >= d->t_max) || (fabs(x[7]) > max_theta) || (fabs(x[6]) > max_phi) || (x[9] < 50.0);
+    if (done) reward += -1.0 / dt * (d->t_max - t) * 2.0;
+    t += dt;
+    if (d->actions) for (int i = 0; i < 3; ++i) d->actions[((size_t)e * d->max_steps + k) * 3 + i] = u[i];
+    if (d->states) for (int i = 0; i < 12; ++i) d->states[((size_t)e * d->max_steps + k) * 12 + i] = x[i];
+    if (d->rewards) d->rewards[(size_t)e * d->max_steps + k] = reward;
+    if (d->transitions) {
+      float *tr = d->transitions + ((size_t)e * d->max_steps + k) * 20;
+      for (int i = 0; i < 7; ++i) tr[i] = (float)obs[i];
+      for (int i = 0; i < 3; ++i) tr[7 + i] = a[i];
+      for (int i = 0; i < 7; ++i) tr[10 + i] = (float)nobs[i];
+      tr[17] = (float)reward; tr[18] = done ? 1.0f : 0.0f; tr[19] = cost ? 1.0f : 0.0f;
+    }
+    fitness += reward;
+    cost_steps += cost;
+    memcpy(obs, nobs, sizeof(obs));
+    ++k;
+  }
+  d->fitness[e] = fitness;
+  d->length_steps[e] = k;
+  d->length_t[e] = t;
+  d->cost_steps[e] = cost_steps;
+  return 0;
+}
+
+typedef struct { const serl_rollout_desc *d; const serl_build_desc *bd; int e0, e1, stride, rc; } job_t;
+
+static void *worker(void *p)
+{
+  job_t *j = (job_t *)p;
+  CitInstance *I = (CitInstance *)malloc((size_t)cit_instance_size());
+  float *hbuf = (float *)malloc(sizeof(float) * 2 * (size_t)j->d->hidden);
+  for (int e = j->e0; e < j->e1; e += j->stride) {
+    int rc = run_episode(j->d, j->bd, e, I, hbuf);
+    if (rc) j->rc = rc;
+  }
+  free(hbuf); free(I);
+  return NULL;
+}
+
+/* Same descriptor as serl_rollout (include/serl_amd.h) with host pointers; `threads` host threads
+ * split the episodes round-robin (each thread owns a private dynamics instance). */
+int serl_oracle_rollout(const serl_build_desc *bd, const serl_rollout_desc *d, int threads)
+{
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  pthread_t th[256]; job_t jobs[256];
+  for (int i = 0; i < threads; ++i) {
+    jobs[i] = (job_t){d, bd, i, d->n_episodes, threads, 0};
+    if (threads == 1) worker(&jobs[i]);
+    else pthread_create(&th[i], NULL, worker, &jobs[i]);
+  }
+  int rc = 0;
+  for (int i = 0; i < threads; ++i) {
+    if (threads > 1) pthread_join(th[i], NULL);
+    if (jobs[i].rc) rc = jobs[i].rc;
+  }
+  return rc;
+}

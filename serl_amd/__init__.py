@@ -1,0 +1,24 @@
+"""serl_amd -- MI355X-native population-rollout fitness evaluator behind SERL's own API surface.
+
+Only what the hot path needs: the HIP extension (csrc/, C ABI in include/serl_amd.h)
+and the host-side mirror of the reference interface for this path:
+
+  Actor, GeneticAgent          base/core/genetic_agent.py:10-163   (actor.py)
+  Episode                      base/core/utils.py:12-36            (episode.py)
+  evaluate_pop / RolloutEngine  base/core/agent.py:63-138,229-256  (evaluator.py)
+  make_evaluate                Agent.evaluate-compatible adaptor    (evaluator.py)
+  reference signals            `signals` call sites, envs/phlabenv.py:303-349 (refsignals.py)
+  calc_smoothness / calc_nMAE  base/core/utils.py:39-58,82-120      (metrics.py)
+  SSNE tensor ops              base/core/mod_neuro_evo.py           (ga.py)
+  member sharding + RCCL all-gather of fitness                      (distributed.py)
+
+The HIP extension is mandatory: importing the evaluator on a machine without the built
+library, or calling it without a GPU, raises -- there is no CPU fallback in the product.
+"""
+from .actor import Actor, GeneticAgent, pack_actor, pack_population, NetSpec
+from .episode import Episode
+from .evaluator import RolloutEngine, evaluate_pop, make_evaluate, PopResult
+from . import refsignals, metrics, ga, distributed, builds
+
+__all__ = ['Actor', 'GeneticAgent', 'pack_actor', 'pack_population', 'NetSpec', 'Episode', 'RolloutEngine',
+           'evaluate_pop', 'make_evaluate', 'PopResult', 'refsignals', 'metrics', 'ga', 'distributed', 'builds']

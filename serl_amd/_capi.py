@@ -1,0 +1,72 @@
+"""ctypes loader of the C-ABI HIP extension (include/serl_amd.h).  Fails loudly when the library is
+missing: the product has no CPU path."""
+import ctypes, os
+
+_D = ctypes.POINTER(ctypes.c_double)
+_F = ctypes.POINTER(ctypes.c_float)
+_I = ctypes.POINTER(ctypes.c_int32)
+VP = ctypes.c_void_p
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libserl_amd.so')
+
+EXPORTS = ['serl_abi_version', 'serl_last_error', 'serl_param_count', 'serl_ctx_create', 'serl_ctx_destroy',
+           'serl_ctx_load_build', 'serl_rollout', 'serl_last_rollout_ms', 'serl_ga_clone', 'serl_ga_crossover',
+           'serl_ga_mutate', 'serl_ga_scaled_perturb']
+
+
+class BuildDesc(ctypes.Structure):
+    _fields_ = [('code', ctypes.c_int32), ('n_ro', ctypes.c_int32), ('ro_base', ctypes.c_uint64),
+                ('ro', VP), ('t3', VP), ('x0', VP), ('dw0', VP), ('dt', ctypes.c_double)]
+
+
+class RolloutDesc(ctypes.Structure):
+    _fields_ = [('state_dim', ctypes.c_int32), ('action_dim', ctypes.c_int32), ('hidden', ctypes.c_int32),
+                ('num_layers', ctypes.c_int32), ('activation', ctypes.c_int32), ('n_members', ctypes.c_int32),
+                ('weights', VP), ('weight_stride', ctypes.c_int64),
+                ('n_episodes', ctypes.c_int32), ('build_slot', ctypes.c_int32),
+                ('member_of_episode', VP), ('faults', VP), ('ref', VP), ('ref_stride', ctypes.c_int64),
+                ('err0', VP), ('action_noise', VP), ('t_max', ctypes.c_double),
+                ('max_steps', ctypes.c_int32), ('lanes_per_wave', ctypes.c_int32),
+                ('fitness', VP), ('length_steps', VP), ('length_t', VP), ('cost_steps', VP),
+                ('actions', VP), ('states', VP), ('rewards', VP), ('transitions', VP)]
+
+
+_lib = None
+
+
+class ExtensionMissing(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ExtensionMissing(
+            'serl_amd HIP extension not built: %s is missing. Run `python -c "import __graft_entry__ as g; '
+            'g.build()"` (or `python serl_amd/build.py`). There is no CPU fallback.' % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    L.serl_abi_version.restype = ctypes.c_int
+    L.serl_last_error.restype = ctypes.c_char_p
+    L.serl_param_count.argtypes = [ctypes.c_int] * 4
+    L.serl_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(VP)]
+    L.serl_ctx_destroy.argtypes = [VP]
+    L.serl_ctx_load_build.argtypes = [VP, ctypes.c_int, ctypes.POINTER(BuildDesc)]
+    L.serl_rollout.argtypes = [VP, ctypes.POINTER(RolloutDesc), VP]
+    L.serl_last_rollout_ms.argtypes = [VP, ctypes.POINTER(ctypes.c_float)]
+    L.serl_ga_clone.argtypes = [VP, VP, ctypes.c_int64, ctypes.c_int32, VP, VP, ctypes.c_int32, VP]
+    L.serl_ga_crossover.argtypes = [VP, VP, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, VP, ctypes.c_int32, VP]
+    L.serl_ga_mutate.argtypes = [VP, VP, ctypes.c_int64, ctypes.c_int32, VP, VP, VP, VP, ctypes.c_int32, VP]
+    L.serl_ga_scaled_perturb.argtypes = [VP, VP, ctypes.c_int64, ctypes.c_int32, VP, VP, ctypes.c_int32, VP, VP, VP]
+    for f in EXPORTS:
+        if f not in ('serl_last_error',):
+            getattr(L, f).restype = ctypes.c_int
+    if L.serl_abi_version() != 1:
+        raise RuntimeError('serl_amd: ABI version mismatch')
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, lib().serl_last_error().decode()))

@@ -1,0 +1,53 @@
+"""Compile the HIP extension for gfx950, in-tree (serl_amd/csrc/libserl_amd.so).
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container; the built .so is
+git-ignored but travels to the GPU box with the repo snapshot.
+"""
+import os, subprocess, sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(CSRC, 'libserl_amd.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+UNITS = ['serl_capi.hip', 'rollout_nominal.hip', 'rollout_ice.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-Wno-unused-value']
+
+
+def _deps():
+    out = []
+    for root, _, files in os.walk(CSRC):
+        for f in files:
+            if f.endswith(('.hip', '.h', '.inc')):
+                out.append(os.path.join(root, f))
+    out.append(os.path.join(os.path.dirname(HERE), 'include', 'serl_amd.h'))
+    return out
+
+
+def build(force=False, verbose=False):
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in _deps()):
+        return LIB
+    objdir = os.path.join(CSRC, 'build')
+    os.makedirs(objdir, exist_ok=True)
+
+    def cc(unit):
+        obj = os.path.join(objdir, unit.replace('.hip', '.o'))
+        cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, unit), '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for %s:\n%s' % (unit, r.stderr[-4000:]))
+        if verbose and r.stderr:
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
+        objs = list(ex.map(cc, UNITS))
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs,
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n' + r.stderr[-4000:])
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

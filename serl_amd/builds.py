@@ -1,0 +1,63 @@
+"""Dynamics builds of the reference (`envs/<build>/`), their tables and the env-name grammar.
+
+Data files (serl_amd/data/citation_<build>.npz) hold what the reference binary holds: `.rodata` as f64
+(aero tables rtConstP, rtConstB, literal pool), the post-initialize() images of rtX / rtDW and the
+table3 parameters; extracted by tools/lift/gen_models.py.
+
+Mode grammar follows envs/phlabenv.py:99-172 (`PHlab_<config>_<mode>`, envs/config.py:16-25).
+"""
+import json, os
+import numpy as np
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data')
+CODE_IDS = {'nominal': 0, 'ice': 1, 'cg_timed': 2, 'gust': 3, 'test': 4}
+INF = float('inf')
+
+# mode -> (build directory, actuator-fault row {elev_gain, elev_clip, ail_clip, jam_on, jam, 0,0,0})
+NOMINAL_ROW = (1.0, INF, INF, 0.0, 0.0, 0.0, 0.0, 0.0)
+MODES = {
+    'nominal': ('h2000_v90', NOMINAL_ROW),
+    'h2000-v90': ('h2000_v90', NOMINAL_ROW),
+    'high-q': ('h2000_v150', NOMINAL_ROW), 'h2000-v150': ('h2000_v150', NOMINAL_ROW),
+    'low-q': ('h10000_v90', NOMINAL_ROW), 'h10000-v90': ('h10000_v90', NOMINAL_ROW),
+    'be': ('h2000_v90', (0.3, INF, INF, 0.0, 0.0, 0.0, 0.0, 0.0)),                      # envs/be/citation.py:71-75
+    'jr': ('h2000_v90', (1.0, INF, INF, 1.0, 15 * 3.14159 / 180, 0.0, 0.0, 0.0)),       # envs/jr/citation.py:71-75
+    'sa': ('h2000_v90', (1.0, INF, float(np.deg2rad(1)), 0.0, 0.0, 0.0, 0.0, 0.0)),     # envs/sa/citation.py:73-79
+    'se': ('h2000_v90', (1.0, float(np.deg2rad(2.5)), INF, 0.0, 0.0, 0.0, 0.0, 0.0)),   # envs/se/citation.py:73-79
+    'ice': ('ice', NOMINAL_ROW),
+    'cg': ('cg', NOMINAL_ROW), 'cg-aft': ('cg', NOMINAL_ROW),
+    'cg-for': ('cg_for', NOMINAL_ROW),
+    'cg-shift': ('cg_timed', NOMINAL_ROW), 'cg-timed': ('cg_timed', NOMINAL_ROW),
+    'gust': ('gust', NOMINAL_ROW),
+}
+
+_index = None
+_cache = {}
+
+
+def index():
+    global _index
+    if _index is None:
+        _index = json.load(open(os.path.join(DATA_DIR, 'builds.json')))
+    return _index
+
+
+def load(build):
+    """-> (dict of numpy arrays ro,x0,dw0,t3,dt,ro_base,nB ; index entry {data, code, nB})"""
+    ent = index()[build]
+    key = ent['data']
+    if key not in _cache:
+        z = np.load(os.path.join(DATA_DIR, 'citation_%s.npz' % key))
+        _cache[key] = {k: np.ascontiguousarray(z[k]) for k in z.files}
+    return _cache[key], ent
+
+
+def resolve_mode(mode):
+    """'nominal' | 'be' | 'PHlab_attitude_ice' ... -> (build, fault_row)"""
+    m = mode
+    if m.lower().startswith('phlab_'):
+        m = m.split('_', 2)[2]
+    m = m.lower()
+    if m not in MODES:
+        raise ValueError('unknown PH-LAB mode %r (known: %s)' % (mode, ', '.join(sorted(MODES))))
+    return MODES[m]

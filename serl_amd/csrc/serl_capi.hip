@@ -1,0 +1,250 @@
+// serl_capi.hip -- C ABI (include/serl_amd.h) of the MI355X-native SERL population-rollout evaluator:
+// context / build-table management, rollout dispatch with HIP-event timing, and the SSNE
+// weight-tensor kernels.  No torch types cross this boundary: plain pointers, sizes, a hipStream_t.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "rollout_device.h"
+
+#define SERL_MAX_SLOTS 16
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return fail(SERL_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
+  } while (0)
+
+struct BuildSlot {
+  bool loaded = false;
+  int32_t code = 0;
+  uint64_t ro_base = 0;
+  double dt = 0.01;
+  double *blob = nullptr;   // one device allocation: ro | t3[46] | x0[19] | dw0[31]
+  size_t n_ro = 0;
+};
+
+struct serl_ctx {
+  int device = 0;
+  BuildSlot slots[SERL_MAX_SLOTS];
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+};
+
+void serl_launch_rollout_nominal(const RolloutArgs &a, int grid, hipStream_t stream);
+void serl_launch_rollout_ice(const RolloutArgs &a, int grid, hipStream_t stream);
+
+extern "C" {
+
+int serl_abi_version(void) { return SERL_ABI_VERSION; }
+const char *serl_last_error(void) { return g_err.c_str(); }
+
+int serl_ctx_create(int device, serl_ctx **out)
+{
+  if (!out) return fail(SERL_E_INVALID, "serl_ctx_create: out is NULL");
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return fail(SERL_E_INVALID, "serl_ctx_create: no such device");
+  HIP_TRY(hipSetDevice(device));
+  serl_ctx *c = new (std::nothrow) serl_ctx();
+  if (!c) return fail(SERL_E_NOMEM, "serl_ctx_create: out of memory");
+  c->device = device;
+  HIP_TRY(hipEventCreate(&c->ev0));
+  HIP_TRY(hipEventCreate(&c->ev1));
+  *out = c;
+  return SERL_OK;
+}
+
+int serl_ctx_destroy(serl_ctx *c)
+{
+  if (!c) return SERL_OK;
+  (void)hipSetDevice(c->device);
+  for (auto &s : c->slots) if (s.blob) (void)hipFree(s.blob);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  delete c;
+  return SERL_OK;
+}
+
+int serl_ctx_load_build(serl_ctx *c, int slot, const serl_build_desc *b)
+{
+  if (!c || !b || slot < 0 || slot >= SERL_MAX_SLOTS) return fail(SERL_E_INVALID, "serl_ctx_load_build: bad argument");
+  if (!b->ro || !b->t3 || !b->x0 || !b->dw0 || b->n_ro <= 0) return fail(SERL_E_INVALID, "serl_ctx_load_build: NULL table");
+  if (b->code != SERL_DYN_NOMINAL && b->code != SERL_DYN_ICE)
+    return fail(SERL_E_UNSUPPORTED, "serl_ctx_load_build: dynamics code variant not compiled into this library");
+  HIP_TRY(hipSetDevice(c->device));
+  BuildSlot &s = c->slots[slot];
+  if (s.blob) { HIP_TRY(hipFree(s.blob)); s.blob = nullptr; s.loaded = false; }
+  const size_t n = (size_t)b->n_ro + 46 + 19 + 31;
+  std::vector<double> host(n);
+  memcpy(host.data(), b->ro, sizeof(double) * b->n_ro);
+  memcpy(host.data() + b->n_ro, b->t3, sizeof(double) * 46);
+  memcpy(host.data() + b->n_ro + 46, b->x0, sizeof(double) * 19);
+  memcpy(host.data() + b->n_ro + 65, b->dw0, sizeof(double) * 31);
+  HIP_TRY(hipMalloc((void **)&s.blob, sizeof(double) * n));
+  HIP_TRY(hipMemcpy(s.blob, host.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  s.n_ro = b->n_ro; s.code = b->code; s.ro_base = b->ro_base; s.dt = b->dt; s.loaded = true;
+  return SERL_OK;
+}
+
+int serl_param_count(int S, int H, int L, int A) { return H * S + H + L * (H * H + 3 * H) + A * H + A; }
+
+int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
+{
+  if (!c || !d) return fail(SERL_E_INVALID, "serl_rollout: NULL argument");
+  if (d->build_slot < 0 || d->build_slot >= SERL_MAX_SLOTS || !c->slots[d->build_slot].loaded)
+    return fail(SERL_E_INVALID, "serl_rollout: build slot not loaded");
+  if (d->n_episodes <= 0) return fail(SERL_E_INVALID, "serl_rollout: n_episodes <= 0");
+  if (!d->weights || !d->member_of_episode || !d->ref || !d->fitness || !d->length_steps || !d->length_t || !d->cost_steps)
+    return fail(SERL_E_INVALID, "serl_rollout: required device pointer is NULL");
+  if (d->state_dim != 7 || d->action_dim != 3)
+    return fail(SERL_E_UNSUPPORTED, "serl_rollout: only the PH-LAB attitude task (state_dim 7, action_dim 3) is compiled in");
+  if (d->hidden < 2 || d->hidden > SERL_MAX_HIDDEN || d->num_layers < 0 || d->num_layers > 16)
+    return fail(SERL_E_UNSUPPORTED, "serl_rollout: hidden size / layer count out of range");
+  if (d->activation < 0 || d->activation > 2) return fail(SERL_E_INVALID, "serl_rollout: activation");
+  if (d->weight_stride < serl_param_count(d->state_dim, d->hidden, d->num_layers, d->action_dim))
+    return fail(SERL_E_INVALID, "serl_rollout: weight_stride smaller than the parameter count");
+  if (d->max_steps <= 0) return fail(SERL_E_INVALID, "serl_rollout: max_steps");
+  HIP_TRY(hipSetDevice(c->device));
+  const BuildSlot &s = c->slots[d->build_slot];
+  hipStream_t stream = (hipStream_t)stream_;
+  RolloutArgs a;
+  a.d = *d;
+  a.ro = s.blob; a.t3 = s.blob + s.n_ro; a.x0 = a.t3 + 46; a.dw0 = a.x0 + 19;
+  a.dyn_dt = s.dt;
+  int lanes = d->lanes_per_wave;
+  if (lanes <= 0) {
+    // latency-bound regime: spread episodes over wavefronts until every SIMD of the chip has one
+    // (256 CUs x 4 SIMDs), then start packing lanes
+    lanes = (d->n_episodes + 1023) / 1024;
+  }
+  if (lanes > 64) lanes = 64;
+  a.lanes = lanes;
+  const int grid = (d->n_episodes + lanes - 1) / lanes;
+  HIP_TRY(hipEventRecord(c->ev0, stream));
+  if (s.code == SERL_DYN_NOMINAL) serl_launch_rollout_nominal(a, grid, stream);
+  else serl_launch_rollout_ice(a, grid, stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev1, stream));
+  c->timed = true;
+  return SERL_OK;
+}
+
+int serl_last_rollout_ms(serl_ctx *c, float *ms)
+{
+  if (!c || !ms || !c->timed) return fail(SERL_E_INVALID, "serl_last_rollout_ms: no rollout recorded");
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return SERL_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// SSNE weight-tensor edits (base/core/mod_neuro_evo.py) -- elementwise / row kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void ga_clone_kernel(float *w, int64_t stride, int32_t P, const int32_t *src, const int32_t *dst, int32_t n)
+{
+  const int pair = blockIdx.y;
+  if (pair >= n) return;
+  const float *s = w + (size_t)src[pair] * stride;
+  float *d = w + (size_t)dst[pair] * stride;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+// ops[i] = {offset, length, dir}; applied IN ORDER (later ops see earlier ones, like the reference's
+// sequential row copies), one workgroup, threads stride over the row.
+__global__ void ga_crossover_kernel(float *w, int64_t stride, int32_t ma, int32_t mb, const int32_t *ops, int32_t n_ops)
+{
+  float *a = w + (size_t)ma * stride, *b = w + (size_t)mb * stride;
+  for (int o = 0; o < n_ops; ++o) {
+    const int off = ops[3 * o], len = ops[3 * o + 1], dir = ops[3 * o + 2];
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+      if (dir == 0) a[off + i] = b[off + i]; else b[off + i] = a[off + i];
+    }
+    __syncthreads();
+  }
+}
+
+// Sequential sparse edits of one member (edits may hit the same weight twice; order matters).
+// kind 0: w += z * (strength * w)   [random.gauss(0, strength*w) = z*sigma]   kind 1: w = z
+// followed by the reference's hard clamp to +-1e6 (mod_neuro_evo.py:57-59,366).
+__global__ void ga_mutate_kernel(float *w, int64_t stride, int32_t member, const int32_t *idx, const int32_t *kind,
+                                 const float *z, const float *strength, int32_t n)
+{
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  float *p = w + (size_t)member * stride;
+  for (int i = 0; i < n; ++i) {
+    float v = p[idx[i]];
+    if (kind[i] == 0) v = v + z[i] * (strength[i] * v); else v = z[i];
+    v = fminf(fmaxf(v, -1000000.0f), 1000000.0f);
+    p[idx[i]] = v;
+  }
+}
+
+__global__ void ga_scaled_perturb_kernel(float *w, int64_t stride, int32_t member, const int32_t *seg_off,
+                                         const int32_t *seg_len, int32_t n_seg, const float *delta, const float *scaling)
+{
+  float *p = w + (size_t)member * stride;
+  int base = 0;
+  for (int s = 0; s < n_seg; ++s) {
+    const int off = seg_off[s], len = seg_len[s];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < len; i += gridDim.x * blockDim.x)
+      p[off + i] = p[off + i] + delta[base + i] / scaling[base + i];
+    base += len;
+  }
+}
+
+extern "C" {
+
+int serl_ga_clone(serl_ctx *c, float *weights, int64_t stride, int32_t P, const int32_t *src, const int32_t *dst,
+                  int32_t n, void *stream)
+{
+  if (!c || !weights || !src || !dst || n < 0 || P <= 0) return fail(SERL_E_INVALID, "serl_ga_clone: bad argument");
+  if (n == 0) return SERL_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(ga_clone_kernel, dim3((P + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, weights, stride, P, src, dst, n);
+  HIP_TRY(hipGetLastError());
+  return SERL_OK;
+}
+
+int serl_ga_crossover(serl_ctx *c, float *weights, int64_t stride, int32_t ma, int32_t mb, const int32_t *ops,
+                      int32_t n_ops, void *stream)
+{
+  if (!c || !weights || (!ops && n_ops > 0) || n_ops < 0) return fail(SERL_E_INVALID, "serl_ga_crossover: bad argument");
+  if (n_ops == 0) return SERL_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(ga_crossover_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, weights, stride, ma, mb, ops, n_ops);
+  HIP_TRY(hipGetLastError());
+  return SERL_OK;
+}
+
+int serl_ga_mutate(serl_ctx *c, float *weights, int64_t stride, int32_t member, const int32_t *idx, const int32_t *kind,
+                   const float *z, const float *strength, int32_t n, void *stream)
+{
+  if (!c || !weights || n < 0) return fail(SERL_E_INVALID, "serl_ga_mutate: bad argument");
+  if (n == 0) return SERL_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(ga_mutate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, weights, stride, member, idx, kind, z, strength, n);
+  HIP_TRY(hipGetLastError());
+  return SERL_OK;
+}
+
+int serl_ga_scaled_perturb(serl_ctx *c, float *weights, int64_t stride, int32_t member, const int32_t *seg_offset,
+                           const int32_t *seg_length, int32_t n_seg, const float *delta, const float *scaling, void *stream)
+{
+  if (!c || !weights || !seg_offset || !seg_length || !delta || !scaling || n_seg <= 0)
+    return fail(SERL_E_INVALID, "serl_ga_scaled_perturb: bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(ga_scaled_perturb_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, weights, stride, member,
+                     seg_offset, seg_length, n_seg, delta, scaling);
+  HIP_TRY(hipGetLastError());
+  return SERL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+"""Population rollout on the GPU behind the reference's call shapes.
+
+  RolloutEngine        owns the HIP context (tables of the dynamics builds) on one GPU
+  evaluate_pop(...)    what the GA loop of base/core/agent.py:229-256 (and the eval_pop loop of
+                       base/evaluate.py:242-256) should call: all members x num_evals episodes in one
+                       fused kernel launch -> PopResult (fitness[num_evals, pop], champion index ...)
+  make_evaluate(...)   adaptor with the exact signature of Agent.evaluate (agent.py:63-66), also what
+                       SSNE.__init__ receives as `evaluate` (mod_neuro_evo.py:15,21)
+
+Host code is plumbing: tensors are allocated by PyTorch-ROCm, their raw device pointers and the current
+HIP stream are handed to the C ABI (include/serl_amd.h).
+"""
+import ctypes
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+import numpy as np
+import torch
+
+from . import _capi, builds, refsignals, metrics
+from .actor import NetSpec, pack_population, spec_of
+from .episode import Episode
+
+
+@dataclass
+class PopResult:
+    fitness: np.ndarray          # f64 [num_evals, pop]   episode.fitness (sum of rewards [+ smoothness])
+    returns: np.ndarray          # f64 [num_evals, pop]   plain sum of rewards
+    smoothness: np.ndarray       # f64 [num_evals, pop]
+    length_steps: np.ndarray     # i32 [num_evals, pop]
+    length_t: np.ndarray         # f64 [num_evals, pop]   info['t'] after the last increment
+    cost_steps: np.ndarray       # i32 [num_evals, pop]
+    pop_fitness: np.ndarray      # f64 [pop]  mean over evals (agent.py:245)
+    champion: int                # argmax(pop_fitness)   (agent.py:255)
+    worst: int                   # argmin(pop_fitness)   (agent.py:287)
+    kernel_ms: float = 0.0
+    actions: Optional[torch.Tensor] = None     # f64 [E, T, 3] device, when traces requested
+    states: Optional[torch.Tensor] = None      # f64 [E, T, 12]
+    rewards: Optional[torch.Tensor] = None     # f64 [E, T]
+    transitions: Optional[torch.Tensor] = None  # f32 [E, T, 20]
+    episode_member: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+
+
+class RolloutEngine:
+    """One per process / GPU.  Not thread-safe (one HIP context, calls are stream-ordered)."""
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('serl_amd.RolloutEngine needs a ROCm GPU (torch.cuda.is_available() is False); '
+                               'the product has no CPU path -- the CPU restatement lives in oracle/ for tests only')
+        self.lib = _capi.lib()
+        self.device = torch.device('cuda', torch.cuda.current_device() if device is None else int(device))
+        h = ctypes.c_void_p()
+        _capi.check(self.lib.serl_ctx_create(self.device.index, ctypes.byref(h)), 'serl_ctx_create')
+        self.ctx = h
+        self.slots = {}
+        self.last_kernel_ms = 0.0
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.lib.serl_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def slot_of(self, build):
+        data, ent = builds.load(build)
+        key = ent['data']
+        if key in self.slots:
+            return self.slots[key]
+        slot = len(self.slots)
+        bd = _capi.BuildDesc(code=builds.CODE_IDS[ent['code']], n_ro=len(data['ro']), ro_base=int(data['ro_base']),
+                             ro=data['ro'].ctypes.data, t3=data['t3'].ctypes.data, x0=data['x0'].ctypes.data,
+                             dw0=data['dw0'].ctypes.data, dt=float(data['dt']))
+        _capi.check(self.lib.serl_ctx_load_build(self.ctx, slot, ctypes.byref(bd)), 'serl_ctx_load_build(%s)' % build)
+        self.slots[key] = slot
+        return slot
+
+    # ------------------------------------------------------------------------------------------
+    def rollout(self, weights, spec: NetSpec, member_of_episode, ref, *, build='h2000_v90', faults=None,
+                err0=None, action_noise=None, t_max=80.0, traces=False, transitions=False,
+                lanes_per_wave=0, sync=True):
+        """Low-level: run len(member_of_episode) episodes.  weights f32 [M, >=P] (device or host),
+        ref f64 [E, T, 3] or [T, 3] radians.  Returns dict of device tensors."""
+        dev = self.device
+        w = torch.as_tensor(weights, dtype=torch.float32).to(dev).contiguous()
+        moe = torch.as_tensor(np.asarray(member_of_episode), dtype=torch.int32).to(dev).contiguous()
+        E = moe.numel()
+        ref_t = torch.as_tensor(ref, dtype=torch.float64).to(dev).contiguous()
+        shared = ref_t.dim() == 2
+        T = ref_t.shape[-2]
+        assert ref_t.shape[-1] == 3 and (shared or ref_t.shape[0] == E)
+        out = dict(fitness=torch.zeros(E, dtype=torch.float64, device=dev),
+                   length_steps=torch.zeros(E, dtype=torch.int32, device=dev),
+                   length_t=torch.zeros(E, dtype=torch.float64, device=dev),
+                   cost_steps=torch.zeros(E, dtype=torch.int32, device=dev))
+        d = _capi.RolloutDesc(state_dim=spec.state_dim, action_dim=spec.action_dim, hidden=spec.hidden,
+                              num_layers=spec.num_layers, activation=spec.activation_id, n_members=w.shape[0],
+                              weights=w.data_ptr(), weight_stride=w.stride(0), n_episodes=E,
+                              build_slot=self.slot_of(build), member_of_episode=moe.data_ptr(),
+                              ref=ref_t.data_ptr(), ref_stride=0 if shared else T * 3, t_max=float(t_max),
+                              max_steps=T, lanes_per_wave=int(lanes_per_wave),
+                              fitness=out['fitness'].data_ptr(), length_steps=out['length_steps'].data_ptr(),
+                              length_t=out['length_t'].data_ptr(), cost_steps=out['cost_steps'].data_ptr())
+        keep = [w, moe, ref_t]
+        if faults is not None:
+            f = torch.as_tensor(np.asarray(faults, dtype=np.float64).reshape(E, 8)).to(dev).contiguous()
+            d.faults = f.data_ptr(); keep.append(f)
+        if err0 is not None:
+            e0 = torch.as_tensor(np.asarray(err0, dtype=np.float64).reshape(E, 3)).to(dev).contiguous()
+            d.err0 = e0.data_ptr(); keep.append(e0)
+        if action_noise is not None:
+            an = torch.as_tensor(action_noise, dtype=torch.float64).to(dev).contiguous()
+            assert an.shape == (E, T, 3)
+            d.action_noise = an.data_ptr(); keep.append(an)
+        if traces:
+            out['actions'] = torch.zeros(E, T, 3, dtype=torch.float64, device=dev)
+            out['states'] = torch.zeros(E, T, 12, dtype=torch.float64, device=dev)
+            out['rewards'] = torch.zeros(E, T, dtype=torch.float64, device=dev)
+            d.actions, d.states, d.rewards = out['actions'].data_ptr(), out['states'].data_ptr(), out['rewards'].data_ptr()
+        if transitions:
+            out['transitions'] = torch.zeros(E, T, 20, dtype=torch.float32, device=dev)
+            d.transitions = out['transitions'].data_ptr()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _capi.check(self.lib.serl_rollout(self.ctx, ctypes.byref(d), ctypes.c_void_p(stream)), 'serl_rollout')
+        out['_keep'] = keep
+        if sync:
+            ms = ctypes.c_float()
+            _capi.check(self.lib.serl_last_rollout_ms(self.ctx, ctypes.byref(ms)), 'serl_last_rollout_ms')
+            self.last_kernel_ms = float(ms.value)
+            bad = (out['length_steps'] < 0)
+            if bool(bad.any()):
+                raise RuntimeError('reference table too short: %d episodes were still running after %d steps'
+                                   % (int(bad.sum()), T))
+        return out
+
+    def kernel_ms(self):
+        ms = ctypes.c_float()
+        _capi.check(self.lib.serl_last_rollout_ms(self.ctx, ctypes.byref(ms)), 'serl_last_rollout_ms')
+        self.last_kernel_ms = float(ms.value)
+        return self.last_kernel_ms
+
+
+_default_engine = None
+
+
+def default_engine():
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = RolloutEngine()
+    return _default_engine
+
+
+def _as_weights(actors, spec):
+    if isinstance(actors, torch.Tensor):
+        return actors
+    return pack_population(actors)
+
+
+def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, smooth_fitness=False,
+                 spec: Optional[NetSpec] = None, engine: Optional[RolloutEngine] = None, traces=False,
+                 transitions=False, err0=None, lanes_per_wave=0, need_smoothness=True) -> PopResult:
+    """Evaluate a whole population: `num_evals` episodes per member (agent.py:229-256).
+
+    actors : sequence of Actor / GeneticAgent, or a packed f32 tensor [pop, P] (then pass `spec`)
+    mode   : PH-LAB mode or env name ('nominal', 'be', 'PHlab_attitude_ice', ...; envs/phlabenv.py:99-172);
+             a sequence gives one mode per episode (all must share one dynamics build)
+    refs   : f64 [pop*num_evals, T, 3] / [num_evals, T, 3] / [T, 3] radians tables (refsignals.tabulate);
+             None = the fixed base evaluation reference for every episode
+    Episode order is member-major: e = member*num_evals + eval  (the reference's loop nest)."""
+    engine = engine or default_engine()
+    if spec is None:
+        spec = spec_of(actors[0])
+    w = _as_weights(actors, spec)
+    pop = w.shape[0]
+    E = pop * num_evals
+    moe = np.repeat(np.arange(pop, dtype=np.int32), num_evals)
+    if refs is None:
+        refs = refsignals.tabulate(*refsignals.base_reference(t_max), t_max)
+    refs = torch.as_tensor(refs, dtype=torch.float64)
+    if refs.dim() == 3 and refs.shape[0] == num_evals and num_evals != E:
+        refs = refs.repeat(pop, 1, 1)
+    modes = [mode] * E if isinstance(mode, str) else list(mode)
+    assert len(modes) == E
+    resolved = [builds.resolve_mode(m) for m in modes]
+    blds = {b for b, _ in resolved}
+    if len(blds) != 1:
+        raise ValueError('one evaluate_pop call runs one dynamics build; got %s (split the population by build)' % sorted(blds))
+    faults = None
+    if any(r != builds.NOMINAL_ROW for _, r in resolved):
+        faults = np.array([r for _, r in resolved], dtype=np.float64)
+    need_actions = traces or smooth_fitness or need_smoothness
+    out = engine.rollout(w, spec, moe, refs, build=blds.pop(), faults=faults, err0=err0, t_max=t_max,
+                         traces=need_actions, transitions=transitions, lanes_per_wave=lanes_per_wave)
+    ret = out['fitness'].cpu().numpy()
+    ls = out['length_steps'].cpu().numpy()
+    if need_actions:
+        sm = metrics.calc_smoothness(out['actions'], ls).cpu().numpy()
+    else:
+        sm = np.zeros(E)
+    fit = ret + sm if smooth_fitness else ret.copy()
+    sh = lambda a: np.ascontiguousarray(a.reshape(pop, num_evals).T)
+    fitness = sh(fit)
+    pop_fitness = np.mean(fitness, axis=0)
+    return PopResult(fitness=fitness, returns=sh(ret), smoothness=sh(sm), length_steps=sh(ls),
+                     length_t=sh(out['length_t'].cpu().numpy()), cost_steps=sh(out['cost_steps'].cpu().numpy()),
+                     pop_fitness=pop_fitness, champion=int(np.argmax(pop_fitness)), worst=int(np.argmin(pop_fitness)),
+                     kernel_ms=engine.last_kernel_ms,
+                     actions=out.get('actions') if traces else None, states=out.get('states') if traces else None,
+                     rewards=out.get('rewards') if traces else None, transitions=out.get('transitions'),
+                     episode_member=moe)
+
+
+def make_evaluate(args, *, mode='nominal', t_max=20, ref_fn=None, engine=None, replay_buffer=None, counters=None):
+    """-> evaluate(agent, is_action_noise, store_transition) -> Episode, the signature of
+    Agent.evaluate (base/core/agent.py:63-66).  One episode per call (the batched path is evaluate_pop).
+
+    ref_fn() -> f64 [T,3] radians table for the next episode (default: base reference at t_max).
+    Transitions of stored episodes are appended to `replay_buffer`, `agent.buffer` and (cost steps)
+    `agent.critical_buffer` exactly as agent.py:101-112 does; `counters` (dict) receives
+    num_frames / gen_frames / num_episodes increments."""
+    engine = engine or default_engine()
+    counters = counters if counters is not None else {}
+    state = {'err': np.zeros(3)}   # envs/phlabenv.py never clears self.error between episodes
+
+    def evaluate(agent, is_action_noise: bool, store_transition: bool) -> Episode:
+        actor = agent.actor if hasattr(agent, 'actor') else agent
+        actor.eval()
+        spec = spec_of(actor)
+        ref = ref_fn() if ref_fn is not None else refsignals.tabulate(*refsignals.base_reference(t_max), t_max)
+        T = ref.shape[0]
+        noise = None
+        if is_action_noise:
+            # agent.py:90-93, drawn up-front in the same order the reference draws it per step
+            noise = np.clip(args.noise_sd * np.random.randn(T, 3), -args.noise_clip, args.noise_clip)[None]
+        build, row = builds.resolve_mode(mode)
+        out = engine.rollout(pack_population([actor]), spec, [0], ref, build=build,
+                             faults=None if row == builds.NOMINAL_ROW else [row], err0=state['err'][None],
+                             action_noise=noise, t_max=t_max, traces=True, transitions=store_transition)
+        n = int(out['length_steps'][0])
+        actions = out['actions'][0, :n].cpu().numpy()
+        rewards = out['rewards'][0, :n].cpu().numpy()
+        states = out['states'][0, :n].cpu().numpy()
+        state['err'] = ref[n - 1] - states[n - 1][[7, 6, 5]]
+        if store_transition:
+            tr = out['transitions'][0, :n].cpu().numpy()
+            for row_ in tr:
+                t5 = (row_[0:7].astype(np.float64), row_[7:10], row_[10:17].astype(np.float64), float(row_[17]), float(row_[18]))
+                if replay_buffer is not None:
+                    replay_buffer.add(*t5)
+                if getattr(agent, 'buffer', None) is not None:
+                    agent.buffer.add(*t5)
+                if row_[19] and getattr(agent, 'critical_buffer', None) is not None:
+                    agent.critical_buffer.add(*t5)
+            counters['num_frames'] = counters.get('num_frames', 0) + n
+            counters['gen_frames'] = counters.get('gen_frames', 0) + n
+            counters['num_episodes'] = counters.get('num_episodes', 0) + 1
+        smooth = float(metrics.calc_smoothness(actions[None], [n])[0])
+        fitness = float(np.sum(rewards))
+        if getattr(args, 'smooth_fitness', False):
+            fitness += smooth
+        return Episode(fitness=fitness, smoothness=smooth, length=float(out['length_t'][0]),
+                       state_history=[] if store_transition else list(states), ref_signals=ref[n - 1],
+                       actions=actions, reward_lst=list(rewards))
+
+    return evaluate

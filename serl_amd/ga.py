@@ -1,0 +1,123 @@
+"""SSNE weight-tensor edits (base/core/mod_neuro_evo.py) on a device-resident population tensor.
+
+The population lives as one f32 tensor `weights[pop, P]` (packed rows, actor.NetSpec.param_layout).
+Selection and every random draw stay on the host and consume the *same* RNG streams in the *same*
+order as the reference (python `random`, `numpy.random`), so index decisions are identical; only the
+tensor edits run as HIP kernels (C ABI `serl_ga_*`).
+
+Reference quirks kept: `random.randint(0, n)` is inclusive, so the reference can index
+one past the end (`:76,89,357-358`) and raise IndexError mid-operator; here such a draw is consumed
+(RNG parity) and the edit skipped.
+"""
+import ctypes, math, random
+import numpy as np
+import torch
+from . import _capi
+from .actor import NetSpec
+
+
+def _i32(dev, a):
+    return torch.as_tensor(np.asarray(a, dtype=np.int32)).to(dev)
+
+
+def _f32(dev, a):
+    return torch.as_tensor(np.asarray(a, dtype=np.float32)).to(dev)
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def clone(engine, weights, src, dst, spec: NetSpec):
+    """weights[dst[i]] <- weights[src[i]]  (SSNE.clone, mod_neuro_evo.py:371-382; parameter part)."""
+    src, dst = np.atleast_1d(src), np.atleast_1d(dst)
+    s, d = _i32(weights.device, src), _i32(weights.device, dst)
+    _capi.check(engine.lib.serl_ga_clone(engine.ctx, weights.data_ptr(), weights.stride(0), spec.param_count,
+                                         s.data_ptr(), d.data_ptr(), len(src), _stream(weights.device)), 'serl_ga_clone')
+
+
+def plan_crossover(spec: NetSpec, rng=random):
+    """Draw the op list of crossover_inplace (mod_neuro_evo.py:61-93) -> int32 [n, 3] (offset, length, dir)
+    dir 0: gene1 <- gene2, dir 1: gene2 <- gene1."""
+    ops = []
+    for name, off, shape in spec.param_layout():
+        rows = shape[0]
+        if len(shape) == 2:
+            n = rng.randint(0, rows * 2)
+            width = shape[1]
+        else:
+            n = rng.randint(0, rows)
+            width = 1
+        for _ in range(n):
+            receiver = rng.random()
+            ind = rng.randint(0, rows)
+            if ind >= rows:
+                continue          # the reference raises IndexError here
+            ops.append((off + ind * width, width, 0 if receiver < 0.5 else 1))
+    return np.asarray(ops, dtype=np.int32).reshape(-1, 3)
+
+
+def crossover_inplace(engine, weights, member_a, member_b, spec: NetSpec, rng=random, ops=None):
+    ops = plan_crossover(spec, rng) if ops is None else ops
+    if len(ops):
+        o = _i32(weights.device, ops)
+        _capi.check(engine.lib.serl_ga_crossover(engine.ctx, weights.data_ptr(), weights.stride(0), int(member_a),
+                                                 int(member_b), o.data_ptr(), len(ops), _stream(weights.device)),
+                    'serl_ga_crossover')
+    return ops
+
+
+def plan_mutation(spec: NetSpec, mag, rng=random, nprng=np.random):
+    """Draw the edit list of mutate_inplace (mod_neuro_evo.py:329-369) -> (idx, kind, z, strength)."""
+    num_mutation_frac, super_mut_strength, super_mut_prob = 0.1, 10 * mag, 0.05
+    reset_prob = super_mut_prob + 0.05
+    layout = spec.param_layout()
+    probs = nprng.uniform(0, 1, len(layout)) * 2
+    idx, kind, z, strength = [], [], [], []
+    for i, (name, off, shape) in enumerate(layout):
+        if len(shape) != 2:
+            continue
+        num_weights = shape[0] * shape[1]
+        if rng.random() < probs[i]:
+            for _ in range(rng.randint(0, int(math.ceil(num_mutation_frac * num_weights)))):
+                d1 = rng.randint(0, shape[0])
+                d2 = rng.randint(0, shape[-1])
+                r = rng.random()
+                g = rng.gauss(0, 1.0)           # random.gauss(0, sigma) == sigma * this draw
+                if d1 >= shape[0] or d2 >= shape[1]:
+                    continue                    # the reference raises IndexError here
+                idx.append(off + d1 * shape[1] + d2)
+                if r < super_mut_prob:
+                    kind.append(0); strength.append(super_mut_strength)
+                elif r < reset_prob:
+                    kind.append(1); strength.append(0.0)
+                else:
+                    kind.append(0); strength.append(mag)
+                z.append(g)
+    return (np.asarray(idx, np.int32), np.asarray(kind, np.int32), np.asarray(z, np.float32),
+            np.asarray(strength, np.float32))
+
+
+def mutate_inplace(engine, weights, member, spec: NetSpec, mag, rng=random, nprng=np.random, plan=None):
+    idx, kind, z, strength = plan_mutation(spec, mag, rng, nprng) if plan is None else plan
+    if len(idx):
+        dev = weights.device
+        a, b, c, d = _i32(dev, idx), _i32(dev, kind), _f32(dev, z), _f32(dev, strength)
+        _capi.check(engine.lib.serl_ga_mutate(engine.ctx, weights.data_ptr(), weights.stride(0), int(member),
+                                              a.data_ptr(), b.data_ptr(), c.data_ptr(), d.data_ptr(), len(idx),
+                                              _stream(dev)), 'serl_ga_mutate')
+    return idx, kind, z, strength
+
+
+def scaled_perturb(engine, weights, member, spec: NetSpec, delta, scaling):
+    """theta <- theta + delta / scaling over the 2-D-weights genome (proximal_mutate / safe_mutate update,
+    mod_neuro_evo.py:183-223, 254-298; the Jacobian-based `scaling` comes from torch.autograd)."""
+    segs = spec.genome_segments()
+    dev = weights.device
+    so, sl = _i32(dev, [s[0] for s in segs]), _i32(dev, [s[1] for s in segs])
+    dl = torch.as_tensor(delta, dtype=torch.float32).to(dev).contiguous()
+    sc = torch.as_tensor(scaling, dtype=torch.float32).to(dev).contiguous()
+    assert dl.numel() == sc.numel() == sum(s[1] for s in segs)
+    _capi.check(engine.lib.serl_ga_scaled_perturb(engine.ctx, weights.data_ptr(), weights.stride(0), int(member),
+                                                  so.data_ptr(), sl.data_ptr(), len(segs), dl.data_ptr(), sc.data_ptr(),
+                                                  _stream(dev)), 'serl_ga_scaled_perturb')

@@ -1,0 +1,37 @@
+"""Episode metrics of the reference, batched on the device with torch.fft (rocFFT):
+calc_smoothness (base/core/utils.py:82-120) and calc_nMAE (base/core/utils.py:39-58)."""
+import math
+import torch
+
+
+def calc_smoothness(actions, lengths=None, dt=0.01):
+    """actions: f64 [E, T, A] (rows past an episode's length ignored); lengths: int [E] (None = T).
+    Per episode with N steps: Y = fft(y, N); Syy = |Y[1:N//2]|^2 * dt; S = sum_j sum_i Syy[i,j] * f_i * 2/N
+    with f = linspace(dt, 1/(2dt), N//2 - 1); returns -sqrt(S) * 100 * (80 / (N*dt))  as f64 [E]."""
+    actions = torch.as_tensor(actions, dtype=torch.float64)
+    E, T, A = actions.shape
+    if lengths is None:
+        lengths = torch.full((E,), T, dtype=torch.int64)
+    lengths = torch.as_tensor(lengths).to(torch.int64).cpu()
+    out = torch.empty(E, dtype=torch.float64, device=actions.device)
+    for N in torch.unique(lengths).tolist():      # one batched FFT per distinct episode length
+        idx = torch.nonzero(lengths == N).flatten().to(actions.device)
+        if N < 4:
+            out[idx] = 0.0
+            continue
+        y = actions.index_select(0, idx)[:, :N, :]
+        Y = torch.fft.fft(y, n=N, dim=1)[:, 1:N // 2, :]
+        Syy = (Y * Y.conj()).abs() * dt
+        freq = torch.linspace(dt, 1 / (2 * dt), N // 2 - 1, dtype=torch.float64, device=actions.device)
+        rough = torch.einsum('eij,i->ej', Syy, freq) * 2 / N
+        out[idx] = -(torch.sqrt(rough.sum(-1)) * 100 * (80 / (N * dt)))
+    return out
+
+
+def calc_nMAE(errors):
+    """errors: f64 [T, 3] (ref - controlled state) -> nMAE in percent."""
+    errors = torch.as_tensor(errors, dtype=torch.float64)
+    mae = errors.abs().mean(0)
+    beta_range = max(abs(float(errors[:, -1].mean())), 3.14159 / 180)
+    rng = torch.tensor([math.radians(20), math.radians(20), beta_range], dtype=torch.float64, device=errors.device)
+    return float((mae / rng).mean() * 100)
