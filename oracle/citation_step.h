@@ -14,6 +14,13 @@
 #error "define CIT_MODEL, CIT_DERIV and CIT_STEP before including citation_step.h"
 #endif
 
+#ifndef CIT_POISON
+#ifdef CIT_POISON_B   /* debug: prove that no block signal carries state from one model evaluation to the next */
+#define CIT_POISON(c) do { for (int i_ = 0; i_ < CIT_MAX_NB; ++i_) (c)->B[i_] = NAN; } while (0)
+#else
+#define CIT_POISON(c) ((void)0)
+#endif
+#endif
 #ifndef CIT_ODE5_TABLES
 #define CIT_ODE5_TABLES
 static const double cit_ode5_A[6] = {0.2, 0.3, 0.8, 0.8888888888888888, 1.0, 1.0};
@@ -33,6 +40,7 @@ static inline void CIT_STEP(CitCtx *c, const double *cmd, double *out)
 {
   double y[19], f[6][19];
   c->major = 1;
+  CIT_POISON(c);
   CIT_MODEL(c, cmd, out);            /* stop_time=(tick+1)*dt; outputs; rtY latch; Derivative banks; out=rtY */
   const double t0 = c->t, tnew = c->stop_time, h = c->dt;
   c->major = 0;
@@ -47,6 +55,7 @@ static inline void CIT_STEP(CitCtx *c, const double *cmd, double *out)
       c->X[i] = acc + y[i];
     }
     c->t = (s == 4) ? tnew : (s == 0 ? hB[0] + t0 : h * cit_ode5_A[s] + t0);
+    CIT_POISON(c);
     CIT_MODEL(c, cmd, out);
     CIT_DERIV(c, f[s + 1]);
   }

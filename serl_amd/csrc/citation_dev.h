@@ -32,7 +32,20 @@ struct CitCtx {
   const double *t3;      // table3 parameters P1[3] P2[4] P3[3] P4[36]
 };
 
-#define LIFT_FN static __device__
+// inlining policy: the model body, derivatives and the S-function bodies are inlined into the step
+// function so that the block-signal array B (a local there) is promoted to registers; table lookups and
+// rt_powd_snf stay out of line (they only read the shared tables).
+#define LIFT_INLINE static __device__ __forceinline__
+#define LIFT_OUTLINE static __device__ __noinline__
+#define LIFT_FN_rt_GetLookupIndex LIFT_INLINE
+#define LIFT_FN_rt_Lookup LIFT_OUTLINE
+#define LIFT_FN_rt_Lookup2D_Normal LIFT_OUTLINE
+#define LIFT_FN_rt_powd_snf LIFT_OUTLINE
+#define LIFT_FN_matmultiply LIFT_INLINE
+#define LIFT_FN_ac_atmos LIFT_INLINE
+#define LIFT_FN_ac_axes LIFT_INLINE
+#define LIFT_FN_derivatives LIFT_INLINE
+#define LIFT_FN_model LIFT_INLINE
 static __device__ __forceinline__ uint64_t d2u(double d) { return (uint64_t)__double_as_longlong(d); }
 static __device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
 
@@ -81,7 +94,7 @@ static __device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_
 // The reference walks linearly from the interval cached in IWORK/RWORK; the interval it ends on is
 // i = clamp(max{i : tab[i] < x}, 0, n-2) whatever the cache holds, so only the observable part of the
 // cache (RWORK/IWORK values, which are part of rtDW) is kept.
-static __device__ inline int cit_t3_search(const double *tab, int n, double x, double *rwork, int32_t *iwork)
+static __device__ __forceinline__ int cit_t3_search(const double *tab, int n, double x, double *rwork, int32_t *iwork)
 {
   int idx = *iwork, interval;
   if (x >= *rwork) {
@@ -100,7 +113,7 @@ static __device__ inline int cit_t3_search(const double *tab, int n, double x, d
 }
 
 // Table2 @0x10a30: bilinear interpolation on one slab, tab[(ix+k)*M + j]
-static __device__ inline double cit_table2(const double *xtab, const double *ytab, int ix, int iy,
+static __device__ __forceinline__ double cit_table2(const double *xtab, const double *ytab, int ix, int iy,
                                            const double *tab, int M, double x, double y)
 {
   double rows[2];
@@ -119,7 +132,7 @@ static __device__ inline double cit_table2(const double *xtab, const double *yta
   return d + rows[0];
 }
 
-static __device__ inline void cit_table3(CitCtx *c, const double *u0, const double *u1, const double *u2, double *y)
+static __device__ __forceinline__ void cit_table3(CitCtx *c, const double *u0, const double *u1, const double *u2, double *y)
 {
   const double *P1 = c->t3, *P2 = c->t3 + 3, *P3 = c->t3 + 7, *P4 = c->t3 + 10;
   int i0 = cit_t3_search(P1, 3, *u0, &c->DW[26], &c->IW[0]);

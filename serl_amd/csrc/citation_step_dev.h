@@ -1,29 +1,41 @@
 // citation_step_dev.h -- re-includable: defines CIT_STEP(c, cmd, out), one call of the reference's
 // exported step(cmd[10], out[12]) (major step + ODE5 + clock), on top of the generated
 // CIT_MODEL / CIT_DERIV functions of one code variant.  See citation_dev.h.
+//
+// Structure for the GPU: the six model evaluations of one ODE5 macro step (1 major + 5 minor; the
+// reference recurses into step() for the minor ones, @0xa041..0xa3e7) run as ONE loop around ONE inlined
+// copy of the model body, on a function-local context.  Block signals B never carry state from one
+// evaluation to the next (verified by poisoning them with NaN between evaluations on the CPU restatement
+// for all five code variants), so B lives only in registers; X / DW / rtY / clock are copied in and out.
 #if !defined(CIT_MODEL) || !defined(CIT_DERIV) || !defined(CIT_STEP)
 #error "define CIT_MODEL, CIT_DERIV and CIT_STEP"
 #endif
-static __device__ __noinline__ void CIT_STEP(CitCtx *c, const double *cmd, double *out)
+static __device__ __noinline__ void CIT_STEP(CitCtx *gc, const double *cmd_in, double *out_arg)
 {
-  double y[19], f[6][19];
-  c->major = 1;
-  CIT_MODEL(c, cmd, out);  // stop_time = (tick+1)*dt; outputs; rtY latch; Derivative banks; out = rtY
-  const double t0 = c->t, tnew = c->stop_time, h = c->dt;
-  c->major = 0;
-  for (int i = 0; i < 19; ++i) y[i] = c->X[i];
-  CIT_DERIV(c, f[0]);
-  for (int s = 0; s < 5; ++s) {
-    double hB[6];
-    for (int j = 0; j <= s; ++j) hB[j] = cit_ode5_B[s][j] * h;
-    for (int i = 0; i < 19; ++i) {
-      double acc = f[0][i] * hB[0];
-      for (int j = 1; j <= s; ++j) acc = acc + f[j][i] * hB[j];
-      c->X[i] = acc + y[i];
+  CitCtx lc;
+  double y[19], f[6][19], cmd[10], out[12];
+  for (int i = 0; i < 19; ++i) { lc.X[i] = gc->X[i]; y[i] = lc.X[i]; }
+  for (int i = 0; i < 29; ++i) lc.DW[i] = gc->DW[i];
+  for (int i = 0; i < 4; ++i) lc.IW[i] = gc->IW[i];
+  for (int i = 0; i < 12; ++i) lc.Y[i] = gc->Y[i];
+  for (int i = 0; i < 10; ++i) cmd[i] = cmd_in[i];
+  lc.t = gc->t; lc.stop_time = gc->stop_time; lc.dt = gc->dt; lc.tick = gc->tick;
+  lc.ro = gc->ro; lc.t3 = gc->t3;
+  const double t0 = lc.t, h = lc.dt;
+  for (int s = 0; s < 6; ++s) {
+    if (s > 0) {
+      double hB[6];
+      for (int j = 0; j < s; ++j) hB[j] = cit_ode5_B[s - 1][j] * h;
+      for (int i = 0; i < 19; ++i) {
+        double acc = f[0][i] * hB[0];
+        for (int j = 1; j < s; ++j) acc = acc + f[j][i] * hB[j];
+        lc.X[i] = acc + y[i];
+      }
+      lc.t = (s == 5) ? lc.stop_time : (s == 1 ? hB[0] + t0 : h * cit_ode5_A[s - 1] + t0);
     }
-    c->t = (s == 4) ? tnew : (s == 0 ? hB[0] + t0 : h * cit_ode5_A[s] + t0);
-    CIT_MODEL(c, cmd, out);
-    CIT_DERIV(c, f[s + 1]);
+    lc.major = (s == 0) ? 1 : 0;
+    CIT_MODEL(&lc, cmd, out);   // s == 0: stop_time = (tick+1)*dt; rtY latch; Derivative-block banks
+    CIT_DERIV(&lc, f[s]);
   }
   {
     double hB[6];
@@ -31,12 +43,16 @@ static __device__ __noinline__ void CIT_STEP(CitCtx *c, const double *cmd, doubl
     for (int i = 0; i < 19; ++i) {
       double acc = f[0][i] * hB[0];
       for (int j = 1; j < 6; ++j) acc = acc + f[j][i] * hB[j];
-      c->X[i] = acc + y[i];
+      gc->X[i] = acc + y[i];
     }
   }
-  c->major = 1;
-  c->tick += 1;
-  c->t = tnew;
+  for (int i = 0; i < 29; ++i) gc->DW[i] = lc.DW[i];
+  for (int i = 0; i < 4; ++i) gc->IW[i] = lc.IW[i];
+  for (int i = 0; i < 12; ++i) { gc->Y[i] = lc.Y[i]; out_arg[i] = lc.Y[i]; }
+  gc->major = 1;
+  gc->tick = lc.tick + 1;
+  gc->stop_time = lc.stop_time;
+  gc->t = lc.stop_time;
 }
 #undef CIT_MODEL
 #undef CIT_DERIV

@@ -230,14 +230,18 @@ def lift_build(ref, build, prefix):
                                               extra_params=ROP))
     lift('matmultiply', by['matmultiply'], S(P + 'matmultiply', [('rdi', 'p'), ('rsi', 'p'), ('rdx', 'p')],
                                               'void', extra_params=ROP))
-    lift('mdlOutputs', mdl[0], S(P + 'ac_atmos', [], 'void', entry={'rdi': ('SIMS', 0)},
+    def lift_as(fname, name, addr, spec):
+        em = XL.Emitter(L, funcs[(addr, name)], spec, fname)
+        pieces.append(em.emit())
+
+    lift_as('ac_atmos', 'mdlOutputs', mdl[0], S(P + 'ac_atmos', [], 'void', entry={'rdi': ('SIMS', 0)},
                                  extra_params=ROP + ', const double *su, double *sy'))
-    lift('mdlOutputs', mdl[1], S(P + 'ac_axes', [], 'void', entry={'rdi': ('SIMS', 0)},
+    lift_as('ac_axes', 'mdlOutputs', mdl[1], S(P + 'ac_axes', [], 'void', entry={'rdi': ('SIMS', 0)},
                                  extra_params=ROP + ', const double *su, double *sy, int mode'))
     lift('citation_to_python_derivatives', by['citation_to_python_derivatives'],
          S(P + 'derivatives', [], 'void', extra_params='CitCtx *c, double *xdot',
            ret_expr='const double *ro = c->ro; (void)ro;'))
-    lift('step', by['step'], S(P + 'model', [], 'void', entry={'rdi': ('CMD', 0), 'rsi': ('OUT', 0)},
+    lift_as('model', 'step', by['step'], S(P + 'model', [], 'void', entry={'rdi': ('CMD', 0), 'rsi': ('OUT', 0)},
                                extra_params='CitCtx *c, const double *cmd, double *out',
                                ret_expr='const double *ro = c->ro;'))
 

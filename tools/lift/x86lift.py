@@ -617,7 +617,7 @@ class Emitter:
         if spec.extra_params:
             params.insert(0, spec.extra_params)
         rett = {'void': 'void', 'f': 'double', 'i': 'int64_t'}[spec.ret]
-        head = 'LIFT_FN %s %s(%s)\n{' % (rett, spec.cname, ', '.join(params) or 'void')
+        head = 'LIFT_FN_%s %s %s(%s)\n{' % (self.fname.replace('citation_to_python_', ''), rett, spec.cname, ', '.join(params) or 'void')
         decl = ['  uint64_t ' + ', '.join('%s = 0' % r for r in GPR64 if r != 'rsp') + ';',
                 '  double ' + ', '.join('x%d = 0, x%dh = 0' % (i, i) for i in range(16)) + ';',
                 '  uint64_t fua = 0, fub = 0; int64_t fsa = 0, fsb = 0, fres = 0; double fda = 0, fdb = 0;',
