@@ -114,6 +114,11 @@ int serl_ctx_load_build(serl_ctx *ctx, int slot, const serl_build_desc *build);
 /* One population evaluation: all episodes of the descriptor, one fused kernel launch per call. */
 int serl_rollout(serl_ctx *ctx, const serl_rollout_desc *desc, void *stream);
 
+/* Dynamics only (test / micro-benchmark entry): per episode initialize() followed by T calls of the
+ * reference's step(cmd) -- cmds f64 [n_episodes][T][10] -> states f64 [n_episodes][T][12] (device). */
+int serl_dyn_open_loop(serl_ctx *ctx, int slot, int32_t n_episodes, int32_t T, const double *cmds,
+                       double *states, int32_t lanes_per_wave, void *stream);
+
 /* Duration (ms) of the most recent serl_rollout kernel on its stream, measured with HIP events
  * recorded around the launch; blocks until that kernel has finished. */
 int serl_last_rollout_ms(serl_ctx *ctx, float *ms);

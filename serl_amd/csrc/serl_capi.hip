@@ -38,6 +38,8 @@ struct serl_ctx {
 
 void serl_launch_rollout_nominal(const RolloutArgs &a, int grid, hipStream_t stream);
 void serl_launch_rollout_ice(const RolloutArgs &a, int grid, hipStream_t stream);
+void serl_launch_dyn_nominal(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
+void serl_launch_dyn_ice(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
 
 extern "C" {
 
@@ -129,6 +131,32 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   HIP_TRY(hipEventRecord(c->ev0, stream));
   if (s.code == SERL_DYN_NOMINAL) serl_launch_rollout_nominal(a, grid, stream);
   else serl_launch_rollout_ice(a, grid, stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev1, stream));
+  c->timed = true;
+  return SERL_OK;
+}
+
+int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, const double *cmds, double *states,
+                       int32_t lanes_per_wave, void *stream_)
+{
+  if (!c || !cmds || !states || n_episodes <= 0 || T <= 0) return fail(SERL_E_INVALID, "serl_dyn_open_loop: bad argument");
+  if (slot < 0 || slot >= SERL_MAX_SLOTS || !c->slots[slot].loaded) return fail(SERL_E_INVALID, "serl_dyn_open_loop: build slot not loaded");
+  HIP_TRY(hipSetDevice(c->device));
+  const BuildSlot &s = c->slots[slot];
+  RolloutArgs a;
+  memset(&a, 0, sizeof(a));
+  a.d.n_episodes = n_episodes;
+  a.ro = s.blob; a.t3 = s.blob + s.n_ro; a.x0 = a.t3 + 46; a.dw0 = a.x0 + 19;
+  a.dyn_dt = s.dt;
+  int lanes = lanes_per_wave <= 0 ? (n_episodes + 1023) / 1024 : lanes_per_wave;
+  if (lanes > 64) lanes = 64;
+  a.lanes = lanes;
+  const int grid = (n_episodes + lanes - 1) / lanes;
+  hipStream_t stream = (hipStream_t)stream_;
+  HIP_TRY(hipEventRecord(c->ev0, stream));
+  if (s.code == SERL_DYN_NOMINAL) serl_launch_dyn_nominal(a, cmds, states, T, grid, stream);
+  else serl_launch_dyn_ice(a, cmds, states, T, grid, stream);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, stream));
   c->timed = true;

@@ -137,6 +137,18 @@ class RolloutEngine:
                                    % (int(bad.sum()), T))
         return out
 
+    def dynamics_open_loop(self, cmds, build='h2000_v90', lanes_per_wave=0):
+        """Dynamics only: cmds f64 [E, T, 10] -> states f64 [E, T, 12] (what the reference's raw
+        initialize()/step() return for the same command sequence)."""
+        c = torch.as_tensor(cmds, dtype=torch.float64).to(self.device).contiguous()
+        E, T, _ = c.shape
+        out = torch.zeros(E, T, 12, dtype=torch.float64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _capi.check(self.lib.serl_dyn_open_loop(self.ctx, self.slot_of(build), E, T, c.data_ptr(), out.data_ptr(),
+                                                int(lanes_per_wave), ctypes.c_void_p(stream)), 'serl_dyn_open_loop')
+        self.kernel_ms()
+        return out
+
     def kernel_ms(self):
         ms = ctypes.c_float()
         _capi.check(self.lib.serl_last_rollout_ms(self.ctx, ctypes.byref(ms)), 'serl_last_rollout_ms')
