@@ -18,6 +18,13 @@
 #include <stdint.h>
 
 #define CIT_MAX_NB 648
+#define CIT_SINCOS(x, s, c_) sincos((x), (s), (c_))
+#include "citation_leaves.h"
+
+// Read-only model tables (.rodata words [RO_LO_W, RO_HI_W) of the build: aero tables rtConstP, rtConstB,
+// literal pool; ~94 KiB) are staged once per workgroup into LDS and shared by its wavefronts.
+#define CIT_RO_LDS_WORDS 12040
+__shared__ double g_ro[CIT_RO_LDS_WORDS];
 
 struct CitCtx {
   double X[19];          // p q r V alpha beta phi theta psi he xe ye | washout, 2 consts, 4 engine states
@@ -28,8 +35,10 @@ struct CitCtx {
   double t, stop_time, dt;
   int32_t major;         // simTimeStep: 1 major, 0 minor
   uint32_t tick;         // clockTick0
-  const double *ro;      // .rodata of the build as f64 (rtConstP tables, rtConstB, literal pool)
+  const double *ro;      // unused on the device (tables are staged in LDS: g_ro)
   const double *t3;      // table3 parameters P1[3] P2[4] P3[3] P4[36]
+  CitAxes ax;            // trigonometry + rotation matrices of the current model evaluation
+  int32_t err;           // CIT_ERR_* flags
 };
 
 // inlining policy: the model body, derivatives and the S-function bodies are inlined into the step
@@ -37,19 +46,19 @@ struct CitCtx {
 // rt_powd_snf stay out of line (they only read the shared tables).
 #define LIFT_INLINE static __device__ __forceinline__
 #define LIFT_OUTLINE static __device__ __noinline__
-#define LIFT_FN_rt_GetLookupIndex LIFT_INLINE
-#define LIFT_FN_rt_Lookup LIFT_OUTLINE
-#define LIFT_FN_rt_Lookup2D_Normal LIFT_OUTLINE
+#define LIFT_OMIT_rt_GetLookupIndex   // -> citation_leaves.h
+#define LIFT_OMIT_rt_Lookup
+#define LIFT_OMIT_rt_Lookup2D_Normal
+#define LIFT_OMIT_matmultiply
+#define LIFT_OMIT_ac_axes
 #define LIFT_FN_rt_powd_snf LIFT_OUTLINE
-#define LIFT_FN_matmultiply LIFT_INLINE
 #define LIFT_FN_ac_atmos LIFT_INLINE
-#define LIFT_FN_ac_axes LIFT_INLINE
 #define LIFT_FN_derivatives LIFT_INLINE
 #define LIFT_FN_model LIFT_INLINE
 static __device__ __forceinline__ uint64_t d2u(double d) { return (uint64_t)__double_as_longlong(d); }
 static __device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
 
-#define RO_D(o)    (((double *)ro)[((uint64_t)(o) - RO_BASE) >> 3])
+#define RO_D(o)    (g_ro[((uint64_t)(o) >> 3) - CIT_RO_LO_W])
 #define B_D(o)     (c->B[(uint64_t)(o) >> 3])
 #define X_D(o)     (c->X[(uint64_t)(o) >> 3])
 #define DW_D(o)    (c->DW[(uint64_t)(o) >> 3])
@@ -158,7 +167,7 @@ static __device__ inline void cit_reset(CitCtx *c, const double *ro, const doubl
   const int32_t *iw = (const int32_t *)(dw0 + 29);
   c->IW[0] = iw[0]; c->IW[1] = iw[1]; c->IW[2] = iw[2]; c->IW[3] = 0;
   for (int i = 0; i < 12; ++i) c->Y[i] = 0.0;
-  c->ro = ro; c->t3 = t3; c->dt = dt; c->major = 1; c->tick = 0; c->t = 0.0; c->stop_time = 0.0;
+  c->ro = ro; c->t3 = t3; c->dt = dt; c->major = 1; c->tick = 0; c->t = 0.0; c->stop_time = 0.0; c->err = 0;
 }
 
 // Dormand-Prince "ode5" tableau as the reference's literal pool holds it (0x13688, 0x13898..0x13938)

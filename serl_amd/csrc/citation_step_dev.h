@@ -20,7 +20,7 @@ static __device__ __noinline__ void CIT_STEP(CitCtx *gc, const double *cmd_in, d
   for (int i = 0; i < 12; ++i) lc.Y[i] = gc->Y[i];
   for (int i = 0; i < 10; ++i) cmd[i] = cmd_in[i];
   lc.t = gc->t; lc.stop_time = gc->stop_time; lc.dt = gc->dt; lc.tick = gc->tick;
-  lc.ro = gc->ro; lc.t3 = gc->t3;
+  lc.ro = gc->ro; lc.t3 = gc->t3; lc.err = gc->err;
   const double t0 = lc.t, h = lc.dt;
   for (int s = 0; s < 6; ++s) {
     if (s > 0) {
@@ -34,6 +34,7 @@ static __device__ __noinline__ void CIT_STEP(CitCtx *gc, const double *cmd_in, d
       lc.t = (s == 5) ? lc.stop_time : (s == 1 ? hB[0] + t0 : h * cit_ode5_A[s - 1] + t0);
     }
     lc.major = (s == 0) ? 1 : 0;
+    cit_axes_prepare(&lc.ax, lc.X[4], lc.X[5], lc.X[6], lc.X[7], lc.X[8]);
     CIT_MODEL(&lc, cmd, out);   // s == 0: stop_time = (tick+1)*dt; rtY latch; Derivative-block banks
     CIT_DERIV(&lc, f[s]);
   }
@@ -50,6 +51,7 @@ static __device__ __noinline__ void CIT_STEP(CitCtx *gc, const double *cmd_in, d
   for (int i = 0; i < 4; ++i) gc->IW[i] = lc.IW[i];
   for (int i = 0; i < 12; ++i) { gc->Y[i] = lc.Y[i]; out_arg[i] = lc.Y[i]; }
   gc->major = 1;
+  gc->err = lc.err;
   gc->tick = lc.tick + 1;
   gc->stop_time = lc.stop_time;
   gc->t = lc.stop_time;

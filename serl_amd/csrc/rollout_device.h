@@ -27,6 +27,8 @@ static __device__ __forceinline__ float serl_act(float v, int act)
 }
 
 #define SERL_MAX_HIDDEN 128
+#define SERL_BLOCK 256          // 4 wavefronts per workgroup share one LDS copy of the tables
+#define SERL_WAVES_PER_BLOCK (SERL_BLOCK / 64)
 
 // Actor forward for one lane: sequential f32 accumulation in index order (matches oracle/rollout_ref.c)
 static __device__ void serl_actor_forward(const serl_rollout_desc &d, const float *__restrict__ w,

@@ -124,10 +124,12 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     // latency-bound regime: spread episodes over wavefronts until every SIMD of the chip has one
     // (256 CUs x 4 SIMDs), then start packing lanes
     lanes = (d->n_episodes + 1023) / 1024;
+    if (lanes < 1) lanes = 1;
   }
   if (lanes > 64) lanes = 64;
   a.lanes = lanes;
-  const int grid = (d->n_episodes + lanes - 1) / lanes;
+  const int waves = (d->n_episodes + lanes - 1) / lanes;
+  const int grid = (waves + SERL_WAVES_PER_BLOCK - 1) / SERL_WAVES_PER_BLOCK;
   HIP_TRY(hipEventRecord(c->ev0, stream));
   if (s.code == SERL_DYN_NOMINAL) serl_launch_rollout_nominal(a, grid, stream);
   else serl_launch_rollout_ice(a, grid, stream);
@@ -152,7 +154,7 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
   int lanes = lanes_per_wave <= 0 ? (n_episodes + 1023) / 1024 : lanes_per_wave;
   if (lanes > 64) lanes = 64;
   a.lanes = lanes;
-  const int grid = (n_episodes + lanes - 1) / lanes;
+  const int grid = ((n_episodes + lanes - 1) / lanes + SERL_WAVES_PER_BLOCK - 1) / SERL_WAVES_PER_BLOCK;
   hipStream_t stream = (hipStream_t)stream_;
   HIP_TRY(hipEventRecord(c->ev0, stream));
   if (s.code == SERL_DYN_NOMINAL) serl_launch_dyn_nominal(a, cmds, states, T, grid, stream);

@@ -266,10 +266,14 @@ def lift_build(ref, build, prefix):
            '#define M_I32_0x%x (c->tick)' % tick0_off,
            '#define M_D_0x%x (c->stop_time)' % stop_off,
            '#define M_D_0x%x (c->dt)' % step_sz,
-           '#define CIT_NB %d' % (nB // 8)] + sf_lines
+           '#define CIT_NB %d' % (nB // 8),
+           '#define RO_USED_LO 0x%xULL' % (L.ro_min & ~7),
+           '#define RO_USED_HI 0x%xULL' % (ro_lo + (ro_sz // 8) * 8)] + sf_lines
+    hdr.append('enum { %sRO_BASE_W = 0x%x / 8, %sRO_LO_W = 0x%x / 8, %sRO_HI_W = 0x%x / 8 };  /* f64 word range of .rodata the model reads */'
+               % (P, ro_lo, P, L.ro_min & ~7, P, ro_lo + (ro_sz // 8) * 8))
     body = '\n'.join(hdr) + '\n\n' + '\n'.join(pieces)
     body += '\n#undef RO_BASE\n' + ''.join('#undef SFUN_CALL_%d\n' % k for k in range(len(info['sfun'])))
-    body += ''.join('#undef %s\n' % s for s in ('M_I32_0x%x' % simts_off, 'M_I32_0x%x' % tick0_off,
+    body += ''.join('#undef %s\n' % s for s in ('RO_USED_LO', 'RO_USED_HI', 'M_I32_0x%x' % simts_off, 'M_I32_0x%x' % tick0_off,
                                                'M_D_0x%x' % stop_off, 'M_D_0x%x' % step_sz, 'CIT_NB'))
     meta = dict(build=build, ro_base=ro_lo, ro_count=len(ro), nB=nB // 8, constp=syms['rtConstP'][0],
                 constb=syms['rtConstB'][0], sfun=info['sfun'], cut=cut_addr, outcopy=outcopy,

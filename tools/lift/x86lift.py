@@ -516,6 +516,8 @@ class Emitter:
                              else _SUB[mem['index']][0])
             off = '(int64_t)(' + ' + '.join(terms) + ')'
         self.regions_used.add(region)
+        if region == 'RO' and av[1] is not None:
+            self.L.ro_min = min(getattr(self.L, 'ro_min', 1 << 62), av[1])
         return region, off, av[1]
 
     def ld_d(self, region, off):
@@ -569,6 +571,9 @@ class Emitter:
             raise ValueError('pointer arg %s is not a pointer: %r' % (regname, av))
         self.regions_used.add(region)
         off = '0x%x' % av[1] if av[1] is not None else '(int64_t)%s' % regname
+        if region == 'RO' and av[1] is not None:
+            self.L.ro_min = min(getattr(self.L, 'ro_min', 1 << 62), av[1])
+            self.L.tbl_ptrs = getattr(self.L, 'tbl_ptrs', set()) | {av[1]}
         return '&%s_D(%s)' % (region, off)
 
     # -- main ------------------------------------------------------------------------------------
@@ -635,7 +640,9 @@ class Emitter:
             decl.append('  ' + spec.prolog)
         body = '\n'.join(self.lines)
         tail = '}\n'
-        return head + '\n' + '\n'.join(decl) + '\n' + body + '\n' + tail
+        key = self.fname.replace('citation_to_python_', '')
+        return ('#ifndef LIFT_OMIT_%s\n' % key + head + '\n' + '\n'.join(decl) + '\n' + body + '\n' + tail +
+                '#endif /* LIFT_OMIT_%s */\n' % key)
 
     def emit_ins(self, ins, st):
         L = self.L
