@@ -82,6 +82,14 @@ static __device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_
 #define P_r8_D(o)  (p_r8[(int64_t)(o) >> 3])
 #define M_I32(o)   M_I32_##o
 #define M_D(o)     M_D_##o
+// table lookups: per-breakpoint-vector index caches are locals of the model function (LIFT_IDX_DECL)
+#define LIFT_IDX_DECL(a) double ixu_##a = 0.0; int ixi_##a = -1;
+#define LIFT_L2D(fn, xr, nr, xc, nc, z, u0, u1)                                                        \
+  cit_lookup2d_at(&RO_D(xr), (nr), &RO_D(xc), &RO_D(z),                                                \
+                  cit_lookup_index_cached(&RO_D(xr), (nr), (u0), &ixu_##xr, &ixi_##xr),               \
+                  cit_lookup_index_cached(&RO_D(xc), (nc), (u1), &ixu_##xc, &ixi_##xc), (u0), (u1))
+#define LIFT_L1D(fn, x, n, u, y) \
+  cit_lookup1d_at(&RO_D(x), cit_lookup_index_cached(&RO_D(x), (n), (u), &ixu_##x, &ixi_##x), (u), &RO_D(y))
 #define LIFT_SQRT(x) sqrt(x)
 #define LIFT_POW(x, y) pow(x, y)
 #define LIFT_EXP(x) exp(x)

@@ -48,6 +48,45 @@ CIT_HD int cit_lookup_index(CIT_TBL x, int n, double u)
   return idx > n - 2 ? n - 2 : idx;
 }
 
+// out-of-line copy of the index search (one instance in the code object; reached only on a cache miss)
+#ifndef CIT_NOINLINE
+#define CIT_NOINLINE static __device__ __noinline__
+#endif
+CIT_NOINLINE int cit_lookup_index_slow(CIT_TBL x, int n, double u) { return cit_lookup_index(x, n, u); }
+
+// index with a one-entry cache per breakpoint vector (cu/ci are locals of the model function): within one
+// model evaluation most of the 144 searches repeat an earlier (vector, input) pair (41 distinct, nominal)
+CIT_HD int cit_lookup_index_cached(CIT_TBL x, int n, double u, double *cu, int *ci)
+{
+  if (*ci >= 0 && cit_bits(*cu) == cit_bits(u)) return *ci;
+  const int i = cit_lookup_index_slow(x, n, u);
+  *cu = u; *ci = i;
+  return i;
+}
+
+CIT_HD double cit_lookup1d_at(CIT_TBL x, int i, double u, CIT_TBL y)
+{
+  const double x0 = x[i], x1 = x[i + 1], y0 = y[i], y1 = y[i + 1];
+  double r = y1 - y0;
+  r = r / (x1 - x0);
+  r = r * (u - x0);
+  return r + y0;
+}
+
+CIT_HD double cit_lookup2d_at(CIT_TBL xr, int nr, CIT_TBL xc, CIT_TBL z, int ix, int iy, double u0, double u1)
+{
+  const double x0 = xr[ix], x1 = xr[ix + 1];
+  const double dx = x1 - x0, wx = u0 - x0;
+  const double z00 = z[ix + nr * iy], z10 = z[ix + 1 + nr * iy];
+  const double z01 = z[ix + nr * (iy + 1)], z11 = z[ix + 1 + nr * (iy + 1)];
+  double a = z10 - z00; a = a / dx; a = a * wx; a = a + z00;
+  double b = z11 - z01; b = b / dx; b = b * wx; b = b + z01;
+  const double y0 = xc[iy];
+  const double dy = xc[iy + 1] - y0;
+  double r = b - a; r = r / dy; r = r * (u1 - y0);
+  return r + a;
+}
+
 CIT_HD double cit_lookup1d(CIT_TBL x, int n, double u, CIT_TBL y)
 {
   const int i = cit_lookup_index(x, n, u);

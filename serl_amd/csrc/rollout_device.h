@@ -17,6 +17,7 @@ struct RolloutArgs {
   const double *ro, *t3, *x0, *dw0;   // device copies of the build tables
   double dyn_dt;
   int32_t lanes;                      // active lanes per 64-lane wavefront
+  int32_t block;                      // threads per workgroup (64 x wavefronts sharing one LDS table copy)
 };
 
 static __device__ __forceinline__ float serl_act(float v, int act)
@@ -27,8 +28,7 @@ static __device__ __forceinline__ float serl_act(float v, int act)
 }
 
 #define SERL_MAX_HIDDEN 128
-#define SERL_BLOCK 256          // 4 wavefronts per workgroup share one LDS copy of the tables
-#define SERL_WAVES_PER_BLOCK (SERL_BLOCK / 64)
+#define SERL_BLOCK 256          // launch bound: up to 4 wavefronts (one per SIMD, 512 registers each) per workgroup share one LDS copy of the tables
 
 // Actor forward for one lane: sequential f32 accumulation in index order (matches oracle/rollout_ref.c)
 static __device__ void serl_actor_forward(const serl_rollout_desc &d, const float *__restrict__ w,

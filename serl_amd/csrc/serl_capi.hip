@@ -41,6 +41,17 @@ void serl_launch_rollout_ice(const RolloutArgs &a, int grid, hipStream_t stream)
 void serl_launch_dyn_nominal(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
 void serl_launch_dyn_ice(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
 
+// Wavefronts per workgroup.  One workgroup stages one LDS copy of the tables (94 KiB of the CU's 160 KiB), so
+// only one workgroup fits a CU: while there are no more wavefronts than CUs each gets a CU of its own (the
+// code streams through the instruction cache and co-resident waves slow each other down); beyond that, waves
+// share a CU four at a time (one per SIMD, each with the full 512-register budget).
+static int serl_waves_per_block(int waves)
+{
+  const char *env = getenv("SERL_WAVES_PER_BLOCK");
+  if (env && atoi(env) >= 1 && atoi(env) <= 4) return atoi(env);
+  return waves <= 256 ? 1 : 4;
+}
+
 extern "C" {
 
 int serl_abi_version(void) { return SERL_ABI_VERSION; }
@@ -129,7 +140,9 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   if (lanes > 64) lanes = 64;
   a.lanes = lanes;
   const int waves = (d->n_episodes + lanes - 1) / lanes;
-  const int grid = (waves + SERL_WAVES_PER_BLOCK - 1) / SERL_WAVES_PER_BLOCK;
+  const int wpb = serl_waves_per_block(waves);
+  a.block = 64 * wpb;
+  const int grid = (waves + wpb - 1) / wpb;
   HIP_TRY(hipEventRecord(c->ev0, stream));
   if (s.code == SERL_DYN_NOMINAL) serl_launch_rollout_nominal(a, grid, stream);
   else serl_launch_rollout_ice(a, grid, stream);
@@ -154,7 +167,10 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
   int lanes = lanes_per_wave <= 0 ? (n_episodes + 1023) / 1024 : lanes_per_wave;
   if (lanes > 64) lanes = 64;
   a.lanes = lanes;
-  const int grid = ((n_episodes + lanes - 1) / lanes + SERL_WAVES_PER_BLOCK - 1) / SERL_WAVES_PER_BLOCK;
+  const int nwaves = (n_episodes + lanes - 1) / lanes;
+  const int wpb = serl_waves_per_block(nwaves);
+  a.block = 64 * wpb;
+  const int grid = (nwaves + wpb - 1) / wpb;
   hipStream_t stream = (hipStream_t)stream_;
   HIP_TRY(hipEventRecord(c->ev0, stream));
   if (s.code == SERL_DYN_NOMINAL) serl_launch_dyn_nominal(a, cmds, states, T, grid, stream);

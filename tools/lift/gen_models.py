@@ -233,6 +233,9 @@ def lift_build(ref, build, prefix):
     def lift_as(fname, name, addr, spec):
         em = XL.Emitter(L, funcs[(addr, name)], spec, fname)
         pieces.append(em.emit())
+        for a, n in em.idx_vectors:   # the hand-written GPU index search relies on strict monotonicity
+            v = ro[(a - ro_lo) // 8:(a - ro_lo) // 8 + n]
+            assert n >= 2 and np.all(np.diff(v) > 0), ('breakpoint vector not strictly increasing', hex(a), n, v)
 
     lift_as('ac_atmos', 'mdlOutputs', mdl[0], S(P + 'ac_atmos', [], 'void', entry={'rdi': ('SIMS', 0)},
                                  extra_params=ROP + ', const double *su, double *sy'))

@@ -466,6 +466,7 @@ class Emitter:
         self.fname = fname
         self.lines = []
         self.regions_used = set()
+        self.idx_vectors = set()
         self.frame = 0
 
     # -- helpers ------------------------------------------------------------------------------
@@ -638,6 +639,8 @@ class Emitter:
                 decl.append('  %s = (uint64_t)a_%s;' % (reg, reg))
         if spec.prolog:
             decl.append('  ' + spec.prolog)
+        for a, n in sorted(self.idx_vectors):
+            decl.append('  LIFT_IDX_DECL(0x%x)  /* breakpoint vector, %d entries */' % (a, n))
         body = '\n'.join(self.lines)
         tail = '}\n'
         key = self.fname.replace('citation_to_python_', '')
@@ -946,6 +949,23 @@ class Emitter:
         if spec is None:
             raise ValueError('no call spec for %r' % (key,))
         cname, args, ret = spec
+        # table lookups with compile-time-constant breakpoint/table addresses: emit the macro form so a
+        # flavour can attach per-breakpoint-vector index caches (LIFT_IDX_DECL / LIFT_L2D / LIFT_L1D)
+        base = cname.split('_rt_')[-1] if '_rt_' in cname else ''
+        if base in ('Lookup2D_Normal', 'Lookup'):
+            R = st['r']
+            need = ['rdi', 'rdx', 'r8', 'rsi', 'rcx'] if base == 'Lookup2D_Normal' else ['rdi', 'rdx', 'rsi']
+            if all(R[r][1] is not None for r in need) and all(R[r][0] == 'RO' for r in need if r in ('rdi', 'rdx', 'r8')):
+                for r in ('rdi', 'rdx', 'r8'):
+                    if r in need:
+                        self.L.ro_min = min(getattr(self.L, 'ro_min', 1 << 62), R[r][1])
+                if base == 'Lookup2D_Normal':
+                    self.idx_vectors.add((R['rdi'][1], R['rsi'][1] & 0xffffffff))
+                    self.idx_vectors.add((R['rdx'][1], R['rcx'][1] & 0xffffffff))
+                    return ['x0 = LIFT_L2D(%s, 0x%x, %d, 0x%x, %d, 0x%x, x0, x1);' % (
+                        cname, R['rdi'][1], R['rsi'][1] & 0xffffffff, R['rdx'][1], R['rcx'][1] & 0xffffffff, R['r8'][1])]
+                self.idx_vectors.add((R['rdi'][1], R['rsi'][1] & 0xffffffff))
+                return ['x0 = LIFT_L1D(%s, 0x%x, %d, x0, 0x%x);' % (cname, R['rdi'][1], R['rsi'][1] & 0xffffffff, R['rdx'][1])]
         al = []
         for reg, kind in args:
             if kind == 'ctx':
