@@ -233,6 +233,7 @@ def lift_build(ref, build, prefix):
     def lift_as(fname, name, addr, spec):
         em = XL.Emitter(L, funcs[(addr, name)], spec, fname)
         pieces.append(em.emit())
+        print('   %s: %d loops unrolled at lift time' % (fname, em.n_unrolled))
         for a, n in em.idx_vectors:   # the hand-written GPU index search relies on strict monotonicity
             v = ro[(a - ro_lo) // 8:(a - ro_lo) // 8 + n]
             assert n >= 2 and np.all(np.diff(v) > 0), ('breakpoint vector not strictly increasing', hex(a), n, v)
@@ -325,6 +326,10 @@ def main():
                             ro_base=np.int64(meta['ro_base']))
         index[b] = dict(data=b, code=key, nB=meta['nB'])
         print('build %-10s -> data %s, code %s' % (b, b, key))
+    if a.builds:   # partial run: keep the other entries
+        old = json.load(open(os.path.join(datadir, 'builds.json')))
+        old.update(index)
+        index = old
     json.dump(index, open(os.path.join(datadir, 'builds.json'), 'w'), indent=1, sort_keys=True)
 
 

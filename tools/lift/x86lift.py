@@ -251,6 +251,7 @@ class Lifter:
             for r in ('rax', 'rcx', 'rdx', 'rsi', 'rdi', 'r8', 'r9', 'r10', 'r11'):
                 R[r] = INT
             st['f'] = None
+            st['fc'] = None
             return
         width = 64
         # GPR-affecting instructions
@@ -317,6 +318,7 @@ class Lifter:
             return
         if mn in ('add', 'sub', 'addq', 'subq', 'addl', 'subl'):
             st['f'] = 'res'
+            st['fc'] = None
             src, dst = ops
             if not self.is_reg(dst):
                 return
@@ -350,9 +352,12 @@ class Lifter:
             if dst[1:] in ('rsp',):
                 return  # frame adjustments handled by the emitter (fixed frame)
             setreg(dst[1:], res)
+            if res[1] is not None:
+                st['fc'] = ('res', res[1], w)
             return
         if mn in ('xor', 'and', 'or', 'imul', 'shl', 'shr', 'sar', 'neg', 'not', 'btc', 'inc', 'dec'):
             st['f'] = 'res'
+            st['fc'] = ('res', 0, 64) if (mn == 'xor' and len(ops) == 2 and ops[0] == ops[1]) else None
             dst = ops[-1]
             if self.is_reg(dst):
                 if mn == 'xor' and ops[0] == ops[1]:
@@ -362,9 +367,31 @@ class Lifter:
             return
         if mn in ('cmp', 'cmpl', 'cmpq', 'test', 'testl', 'cmpb', 'testb'):
             st['f'] = 'cmp' if mn.startswith('cmp') else 'test'
+            st['fc'] = None
+            src, dst = ops
+
+            def cval(op):
+                if self.is_imm(op):
+                    return Emitter.simm(op), 64
+                if self.is_reg(op):
+                    av = getreg(op[1:])
+                    return (av[1], _SUB[op[1:]][1]) if av[1] is not None else (None, 64)
+                return None, 64
+            a, wa = cval(dst)
+            b, wb = cval(src)
+            w = min(wa, wb) if (self.is_reg(dst) and self.is_reg(src)) else (wa if self.is_reg(dst) else wb)
+            if mn == 'cmpl':
+                w = 32
+            if a is not None and b is not None:
+                # pointers of the same region compare by offset; mixed region/int compares are not decided
+                ra = getreg(dst[1:])[0] if self.is_reg(dst) else 'int'
+                rb = getreg(src[1:])[0] if self.is_reg(src) else 'int'
+                if ra == rb or 'int' in (ra, rb) and ra == rb:
+                    st['fc'] = (st['f'], a, b, w)
             return
         if mn in ('comisd', 'ucomisd'):
             st['f'] = 'fcmp'
+            st['fc'] = None
             return
         if mn == 'rep_stos':
             R['rcx'] = ('int', 0)
@@ -378,7 +405,7 @@ class Lifter:
 
     def analyse(self, inss, spec):
         idx, leaders = self.build_cfg(inss)
-        entry = {'r': {r: INT for r in GPR64}, 's': {}, 'f': None}
+        entry = {'r': {r: INT for r in GPR64}, 's': {}, 'f': None, 'fc': None}
         entry['r']['rsp'] = ('STK', 0)
         for reg, kind in spec.args:
             if kind == 'p':
@@ -389,7 +416,7 @@ class Lifter:
         work = [inss[0].addr]
         instate = {}
         def copy(st):
-            return {'r': dict(st['r']), 's': dict(st['s']), 'f': st['f']}
+            return {'r': dict(st['r']), 's': dict(st['s']), 'f': st['f'], 'fc': st.get('fc')}
         def merge(addr, st):
             if addr not in states:
                 states[addr] = copy(st); work.append(addr); return
@@ -404,6 +431,8 @@ class Lifter:
                     old['s'][k] = j; changed = True
             if old['f'] != st['f'] and old['f'] is not None:
                 old['f'] = None; changed = True
+            if old.get('fc') != st.get('fc') and old.get('fc') is not None:
+                old['fc'] = None; changed = True
             if changed:
                 work.append(addr)
         cuts = self.rules.get('cuts', {})
@@ -467,6 +496,11 @@ class Emitter:
         self.lines = []
         self.regions_used = set()
         self.idx_vectors = set()
+        self.stk_rd = set()
+        self.stk_addr = set()
+        self.stk_dynamic = False
+        self.labelmap = None
+        self.extra_targets = set()
         self.frame = 0
 
     # -- helpers ------------------------------------------------------------------------------
@@ -522,10 +556,18 @@ class Emitter:
         return region, off, av[1]
 
     def ld_d(self, region, off):
+        if region == 'STK':
+            if off.startswith('0x'):
+                self.stk_rd.add(('d', int(off, 16)))
+                return 'STKS_D(%s)' % off
+            self.stk_dynamic = True
         return '%s_D(%s)' % (region, off)
 
     def st_d(self, region, off, val):
         if region == 'STK':
+            if off.startswith('0x'):
+                return 'STKS_ST_D(%s, %s);' % (off, val)
+            self.stk_dynamic = True
             return 'STK_D(%s) = %s; STK_I(%s) = d2u(%s);' % (off, val, off, val)
         return '%s_D(%s) = %s;' % (region, off, val)
 
@@ -533,6 +575,10 @@ class Emitter:
         if region == 'FS':
             return '0ULL'
         if region == 'STK':
+            if off.startswith('0x'):
+                self.stk_rd.add(('i' if w == 64 else 'w', int(off, 16)))
+                return 'STKS_I(%s)' % off if w == 64 else 'STKS_W(%s)' % off
+            self.stk_dynamic = True
             return 'STK_I(%s)' % off if w == 64 else 'STK_W(%s)' % off
         if region == 'M' or region in self.L.rules.get('int_regions', ()):
             return '%s_I%d(%s)' % (region, w, off)
@@ -542,6 +588,9 @@ class Emitter:
 
     def st_i(self, region, off, val, w):
         if region == 'STK':
+            if off.startswith('0x'):
+                return ('STKS_ST_I(%s, %s);' if w == 64 else 'STKS_ST_W(%s, %s);') % (off, val)
+            self.stk_dynamic = True
             if w == 64:
                 return 'STK_I(%s) = %s; STK_D(%s) = u2d(%s);' % (off, val, off, val)
             return 'STK_W(%s) = (uint32_t)(%s);' % (off, val)
@@ -572,25 +621,299 @@ class Emitter:
             raise ValueError('pointer arg %s is not a pointer: %r' % (regname, av))
         self.regions_used.add(region)
         off = '0x%x' % av[1] if av[1] is not None else '(int64_t)%s' % regname
+        if region == 'STK':
+            if av[1] is None:
+                self.stk_dynamic = True
+            else:
+                self.stk_addr.add(av[1])
+                return '&STKS_D(0x%x)' % av[1]
         if region == 'RO' and av[1] is not None:
             self.L.ro_min = min(getattr(self.L, 'ro_min', 1 << 62), av[1])
             self.L.tbl_ptrs = getattr(self.L, 'tbl_ptrs', set()) | {av[1]}
         return '&%s_D(%s)' % (region, off)
 
     # -- main ------------------------------------------------------------------------------------
+    def lbl(self, addr):
+        return self.labelmap(addr) if self.labelmap else 'L_%x' % addr
+
+    @staticmethod
+    def eval_cc(cc, fc):
+        """decide a condition code from concrete flag operands; None if unknown"""
+        if fc is None:
+            return None
+        def sx(v, w):
+            v &= (1 << w) - 1
+            return v - (1 << w) if v >> (w - 1) else v
+        if fc[0] == 'cmp':
+            _, a, b, w = fc
+            ua, ub = a & ((1 << w) - 1), b & ((1 << w) - 1)
+            sa, sb = sx(a, w), sx(b, w)
+            res = sx(a - b, w)
+            tbl = {'e': ua == ub, 'ne': ua != ub, 'z': ua == ub, 'nz': ua != ub, 'a': ua > ub, 'ae': ua >= ub,
+                   'b': ua < ub, 'be': ua <= ub, 'g': sa > sb, 'ge': sa >= sb, 'l': sa < sb, 'le': sa <= sb,
+                   's': res < 0, 'ns': res >= 0}
+            return tbl.get(cc)
+        if fc[0] == 'test':
+            _, a, b, w = fc
+            res = sx(a & b, w)
+        else:
+            res = sx(fc[1], fc[2])
+        tbl = {'e': res == 0, 'ne': res != 0, 'z': res == 0, 'nz': res != 0, 's': res < 0, 'ns': res >= 0,
+               'le': res <= 0, 'g': res > 0, 'l': res < 0, 'ge': res >= 0}
+        return tbl.get(cc)
+
+    def build_blocks(self, idx, leaders):
+        inss = self.inss
+        starts = sorted(idx[a] for a in leaders if a in idx)
+        blocks = []
+        for n, st in enumerate(starts):
+            en = starts[n + 1] if n + 1 < len(starts) else len(inss)
+            blocks.append((st, en))
+        bid = {inss[st].addr: n for n, (st, en) in enumerate(blocks)}
+        succ = {n: [] for n in range(len(blocks))}
+        for n, (st, en) in enumerate(blocks):
+            last = inss[en - 1]
+            if last.mn == 'ret' or (last.mn == 'call' and last.callname and 'stack_chk_fail' in last.callname):
+                continue
+            if last.mn.startswith('j'):
+                if last.target in bid:
+                    succ[n].append(bid[last.target])
+                if last.mn == 'jmp':
+                    continue
+            if n + 1 < len(blocks):
+                succ[n].append(n + 1)
+        pred = {n: [] for n in range(len(blocks))}
+        for n, ss in succ.items():
+            for t in ss:
+                pred[t].append(n)
+        return blocks, bid, succ, pred
+
+    def find_loops(self, blocks, succ, pred):
+        """natural loops keyed by header block: header -> set(body blocks).  A back edge is an edge whose
+        target dominates its source (address order is no guide: compilers move cold blocks out of line)."""
+        n = len(blocks)
+        reach, stack = set(), [0]
+        while stack:
+            b = stack.pop()
+            if b in reach:
+                continue
+            reach.add(b)
+            stack.extend(succ[b])
+        full = set(reach)
+        dom = {b: set(full) for b in reach}
+        dom[0] = {0}
+        changed = True
+        order = sorted(reach)
+        while changed:
+            changed = False
+            for b in order:
+                if b == 0:
+                    continue
+                ps = [p for p in pred[b] if p in reach]
+                new = set(full)
+                for p in ps:
+                    new &= dom[p]
+                new.add(b)
+                if new != dom[b]:
+                    dom[b] = new
+                    changed = True
+        loops = {}
+        for b in order:
+            for t in succ[b]:
+                if t in dom[b]:      # back edge b -> t
+                    body = {t}
+                    stack = [b]
+                    while stack:
+                        x = stack.pop()
+                        if x in body:
+                            continue
+                        body.add(x)
+                        stack.extend(p for p in pred[x] if p in reach)
+                    loops.setdefault(t, set()).update(body)
+        return loops
+
+    def try_unroll(self, header, body, blocks, bid, succ, pred, instate, copy_state, max_iter=64):
+        """Concrete-integer unrolling of one loop.  Returns a list of emission items or None."""
+        L, inss = self.L, self.inss
+        cuts = L.rules.get('cuts', {})
+        for b in body:
+            st0, en = blocks[b]
+            for i in range(st0, en):
+                if inss[i].addr in cuts or inss[i].mn == 'ret' or inss[i].addr not in instate:
+                    return None
+            if b != header and any(p not in body and inss[blocks[p][0]].addr in instate for p in pred[b]):
+                return None     # entered from outside other than through the header
+        # state on the entry edges
+        entry = None
+        for p_ in pred[header]:
+            if p_ in body:
+                continue
+            st0, en = blocks[p_]
+            if inss[st0].addr not in instate:
+                continue
+            st = copy_state(instate[inss[st0].addr])
+            for i in range(st0, en):
+                if not (inss[i].mn == 'jmp' or inss[i].mn == 'ret'):
+                    L.transfer(st, inss[i])
+            entry = st if entry is None else self.join_states(entry, st)
+        if entry is None:
+            return None
+        # topological order of the body without edges into the header
+        order, seen = [], set()
+        def dfs(b):
+            if b in seen:
+                return
+            seen.add(b)
+            for t in succ[b]:
+                if t in body and t != header:
+                    dfs(t)
+            order.append(b)
+        dfs(header)
+        order.reverse()
+        if set(order) != set(body):
+            return None
+        items = []
+        state_h = entry
+        haddr = inss[blocks[header][0]].addr
+        k = 0
+        while True:
+            bstate = {header: state_h}
+            nxt, exited = None, False
+            def lm(addr, k=k):
+                if addr == haddr:
+                    return 'L_%x_u%d' % (addr, k + 1)
+                if addr in bid and bid[addr] in body:
+                    return 'L_%x_u%d' % (addr, k)
+                return 'L_%x' % addr
+            for b in order:
+                if b not in bstate:
+                    continue
+                st = copy_state(bstate[b])
+                st0, en = blocks[b]
+                items.append(('label', 'L_%x_u%d' % (inss[st0].addr, k)))
+                succs = None
+                for i in range(st0, en):
+                    ins = inss[i]
+                    if ins.mn.startswith('j') and ins.mn != 'jmp':
+                        dec = self.eval_cc(ins.mn[1:], st.get('fc'))
+                        ft = bid.get(inss[en].addr) if en < len(inss) else None
+                        tg = bid.get(ins.target)
+                        if tg is None:
+                            return None
+                        if dec is True:
+                            items.append(('raw', 'goto %s;' % lm(ins.target)))
+                            succs = [tg]
+                        elif dec is False:
+                            succs = [ft]
+                            items.append(('raw', 'goto %s;' % lm(inss[en].addr)))
+                        else:
+                            items.append(('ins', ins, copy_state(st), lm))
+                            items.append(('raw', 'goto %s;' % lm(inss[en].addr)))
+                            succs = [tg, ft]
+                        break
+                    if ins.mn == 'jmp':
+                        tg = bid.get(ins.target)
+                        if tg is None:
+                            return None
+                        items.append(('raw', 'goto %s;' % lm(ins.target)))
+                        succs = [tg]
+                        break
+                    items.append(('ins', ins, copy_state(st), lm))
+                    L.transfer(st, ins)
+                if succs is None:   # fell off the end of the block
+                    if en >= len(inss):
+                        return None
+                    items.append(('raw', 'goto %s;' % lm(inss[en].addr)))
+                    succs = [bid[inss[en].addr]]
+                for t in succs:
+                    if t is None:
+                        return None
+                    if t == header:
+                        nxt = copy_state(st) if nxt is None else self.join_states(nxt, st)
+                    elif t in body:
+                        bstate[t] = copy_state(st) if t not in bstate else self.join_states(bstate[t], st)
+                    else:
+                        exited = True
+                        self.extra_targets.add(inss[blocks[t][0]].addr)
+            if nxt is None:
+                break
+            if exited:
+                return None      # both "continue" and "leave" reachable: trip count is data dependent
+            k += 1
+            if k > max_iter:
+                return None
+            state_h = nxt
+        items.append(('label', 'L_%x_u%d' % (haddr, k + 1)))   # never targeted; keeps label set closed
+        return items
+
+    @staticmethod
+    def join_states(a, b):
+        out = {'r': {}, 's': {}, 'f': a['f'] if a['f'] == b['f'] else None,
+               'fc': a.get('fc') if a.get('fc') == b.get('fc') else None}
+        for r in GPR64:
+            out['r'][r] = join(a['r'][r], b['r'][r])
+        for k_ in a['s']:
+            if k_ in b['s']:
+                out['s'][k_] = join(a['s'][k_], b['s'][k_])
+        return out
+
     def emit(self):
         L = self.L
         idx, leaders, instate = L.analyse(self.inss, self.spec)
         cuts = L.rules.get('cuts', {})
         out = self.lines
-        targets = set()
+        self.labelmap = None
+        self.extra_targets = set()
+
+        def copy_state(st):
+            return {'r': dict(st['r']), 's': dict(st['s']), 'f': st['f'], 'fc': st.get('fc')}
+        blocks, bid, succ, pred = self.build_blocks(idx, leaders)
+        unrolled, skip = {}, set()
+        if L.rules.get('unroll', True):
+            loops = self.find_loops(blocks, succ, pred)
+            for h in sorted(loops):
+                body = loops[h]
+                if any(o != h and o in body for o in loops):    # only innermost loops
+                    continue
+                items = self.try_unroll(h, body, blocks, bid, succ, pred, instate, copy_state)
+                if items is None:
+                    continue
+                unrolled[self.inss[blocks[h][0]].addr] = items
+                for b in body:
+                    for i in range(*blocks[b]):
+                        skip.add(self.inss[i].addr)
+        self.n_unrolled = len(unrolled)
+        targets = set(self.extra_targets)
         for ins in self.inss:
             if ins.mn.startswith('j') and ins.target in idx:
                 targets.add(ins.target)
         for a, c in cuts.items():
             if c[0] == 'goto':
                 targets.add(c[1])
+
+        def put(ins, st):
+            try:
+                stmts = self.emit_ins(ins, st)
+            except Exception as e:
+                raise RuntimeError('%s: at %r: %s' % (self.fname, ins, e))
+            for n_, s_ in enumerate(stmts):
+                out.append('  %s  /* %x %s %s */' % (s_, ins.addr, ins.mn, ins.raw) if n_ == 0 else '  ' + s_)
+
         for ins in self.inss:
+            if ins.addr in unrolled:
+                out.append('L_%x: ;' % ins.addr)
+                for it in unrolled[ins.addr]:
+                    if it[0] == 'label':
+                        out.append('%s: ;' % it[1])
+                    elif it[0] == 'raw':
+                        out.append('  ' + it[1])
+                    else:
+                        self.labelmap = it[3]
+                        put(it[1], it[2])
+                        self.labelmap = None
+                continue
+            if ins.addr in skip:
+                continue
             if ins.addr in targets:
                 out.append('L_%x: ;' % ins.addr)
             if ins.addr not in instate:
@@ -601,13 +924,7 @@ class Emitter:
                 out.append('  /* cut @%x */ %s' % (ins.addr, 'goto L_%x;' % c[1] if c[0] == 'goto' else c[1]))
                 if c[0] == 'goto':
                     continue
-            try:
-                stmts = self.emit_ins(ins, st)
-            except Exception as e:
-                raise RuntimeError('%s: at %r: %s' % (self.fname, ins, e))
-            for s in stmts:
-                out.append('  %s  /* %x %s %s */' % (s, ins.addr, ins.mn, ins.raw) if s is stmts[0]
-                           else '  ' + s)
+            put(ins, st)
         return self.wrap()
 
     def wrap(self):
@@ -628,7 +945,38 @@ class Emitter:
                 '  double ' + ', '.join('x%d = 0, x%dh = 0' % (i, i) for i in range(16)) + ';',
                 '  uint64_t fua = 0, fub = 0; int64_t fsa = 0, fsb = 0, fres = 0; double fda = 0, fdb = 0;',
                 '  (void)fua; (void)fub; (void)fsa; (void)fsb; (void)fres; (void)fda; (void)fdb;']
-        if 'STK' in self.regions_used or self.frame:
+        scalar = not self.stk_dynamic
+        import re as _re
+        if scalar:
+            # every stack access has a constant offset: the x86 spill slots become C scalars
+            rd_d = {o for k_, o in self.stk_rd if k_ == 'd'} | self.stk_addr
+            rd_i = {o for k_, o in self.stk_rd if k_ == 'i'}
+            rd_w = {o for k_, o in self.stk_rd if k_ == 'w'}
+            def sub_st(m):
+                kind, off, val = m.group(1), int(m.group(2), 16), m.group(3)
+                outs = []
+                if kind == 'D':
+                    if off in rd_d: outs.append('sd_0x%x = %s;' % (off, val))
+                    if off in rd_i: outs.append('si_0x%x = d2u(%s);' % (off, val))
+                elif kind == 'I':
+                    if off in rd_i: outs.append('si_0x%x = %s;' % (off, val))
+                    if off in rd_d: outs.append('sd_0x%x = u2d(%s);' % (off, val))
+                else:
+                    if off in rd_w: outs.append('sw_0x%x = (uint32_t)(%s);' % (off, val))
+                return ' '.join(outs) if outs else '/* dead spill store */;'
+            pat = _re.compile(r'STKS_ST_([DIW])\((0x[0-9a-f]+), (.*?)\);')
+            self.lines = [pat.sub(sub_st, ln) for ln in self.lines]
+            self.lines = [_re.sub(r'STKS_D\((0x[0-9a-f]+)\)', r'sd_\1', ln) for ln in self.lines]
+            self.lines = [_re.sub(r'STKS_I\((0x[0-9a-f]+)\)', r'si_\1', ln) for ln in self.lines]
+            self.lines = [_re.sub(r'STKS_W\((0x[0-9a-f]+)\)', r'sw_\1', ln) for ln in self.lines]
+            if rd_d: decl.append('  double ' + ', '.join('sd_0x%x = 0' % o for o in sorted(rd_d)) + ';')
+            if rd_i: decl.append('  uint64_t ' + ', '.join('si_0x%x = 0' % o for o in sorted(rd_i)) + ';')
+            if rd_w: decl.append('  uint32_t ' + ', '.join('sw_0x%x = 0' % o for o in sorted(rd_w)) + ';')
+        else:
+            self.lines = [_re.sub(r'STKS_ST_D\((0x[0-9a-f]+), (.*?)\);', r'STK_D(\1) = \2; STK_I(\1) = d2u(\2);', ln) for ln in self.lines]
+            self.lines = [_re.sub(r'STKS_ST_I\((0x[0-9a-f]+), (.*?)\);', r'STK_I(\1) = \2; STK_D(\1) = u2d(\2);', ln) for ln in self.lines]
+            self.lines = [_re.sub(r'STKS_ST_W\((0x[0-9a-f]+), (.*?)\);', r'STK_W(\1) = (uint32_t)(\2);', ln) for ln in self.lines]
+            self.lines = [_re.sub(r'STKS_([DIW])\(', r'STK_\1(', ln) for ln in self.lines]
             n = (self.frame + 0x40) // 8
             decl.append('  double stk_d[%d]; uint64_t stk_i[%d]; uint32_t stk_w[%d];' % (n, n, 2 * n))
             decl.append('  (void)stk_d; (void)stk_i; (void)stk_w;')
@@ -664,9 +1012,9 @@ class Emitter:
                 # tail call: call + return
                 return self.emit_call(ins, st) + [
                     {'void': 'return;', 'f': 'return x0;', 'i': 'return (int64_t)rax;'}[self.spec.ret]]
-            return ['goto L_%x;' % ins.target]
+            return ['goto %s;' % self.lbl(ins.target)]
         if mn.startswith('j'):
-            return ['if (%s) goto L_%x;' % (self.cond(mn[1:], st, ins), ins.target)]
+            return ['if (%s) goto %s;' % (self.cond(mn[1:], st, ins), self.lbl(ins.target))]
         if mn.startswith('set') and len(ops) == 1 and isreg(ops[0]):
             return [self.reg_write(ops[0][1:], '(%s) ? 1 : 0' % self.cond(mn[3:], st, ins))]
         if mn in ('movzbl', 'movzwl'):
@@ -917,6 +1265,15 @@ class Emitter:
                 raise ValueError('rep stos dest')
             region = av[0]
             self.regions_used.add(region)
+            cnt = st['r']['rcx']
+            if av[1] is not None and cnt[1] is not None and cnt[1] <= 64:
+                outl = []
+                for k_ in range(cnt[1]):
+                    outl.append(self.st_i(region, '0x%x' % (av[1] + 8 * k_), 'rax', 64))
+                outl.append('rdi += 8 * rcx; rcx = 0;')
+                return outl
+            if region == 'STK':
+                self.stk_dynamic = True
             return ['{ uint64_t k_; for (k_ = 0; k_ < rcx; ++k_) { %s } rdi += 8 * rcx; rcx = 0; }' %
                     self.st_i(region, '(int64_t)(rdi + 8 * k_)', 'rax', 64)]
         raise ValueError('emit: unhandled instruction')
