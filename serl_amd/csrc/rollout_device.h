@@ -30,40 +30,70 @@ static __device__ __forceinline__ float serl_act(float v, int act)
 #define SERL_MAX_HIDDEN 128
 #define SERL_BLOCK 256          // launch bound: up to 4 wavefronts (one per SIMD, 512 registers each) per workgroup share one LDS copy of the tables
 
-// Actor forward for one lane: sequential f32 accumulation in index order (matches oracle/rollout_ref.c)
-static __device__ void serl_actor_forward(const serl_rollout_desc &d, const float *__restrict__ w,
-                                          const float *obs, float *act_out)
+// ---- actor MLP, wave-cooperative ----------------------------------------------------------------
+// One forward pass of ONE member's actor by all 64 lanes of a wavefront: lane r owns hidden rows r and
+// r+64; the previous layer's activations are broadcast lane-by-lane with v_readlane (the loop index is
+// wave-uniform), so every row accumulates  acc = bias; acc += W[i][j]*h[j]  in index order j = 0..n-1 with
+// separate multiply and add -- bit-identical to the sequential restatement in oracle/rollout_ref.c.
+// LayerNorm (base/core/mod_utils.py:39-50): mean and the unbiased variance are summed in index order too
+// (every lane redundantly), std = sqrt(var/(H-1)), y = gamma*(x-mean)/(std+1e-6)+beta.
+// `w`, `obs` and the result are wave-uniform.
+static __device__ __forceinline__ float serl_bcast(float v, int srclane)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
+}
+
+static __device__ void serl_actor_forward_wave(const serl_rollout_desc &d, const float *__restrict__ w,
+                                               const float obs[7], float act_out[3])
 {
   const int S = d.state_dim, H = d.hidden, A = d.action_dim, L = d.num_layers;
-  float h0[SERL_MAX_HIDDEN], h1[SERL_MAX_HIDDEN];
-  const float *W = w, *b = w + (size_t)H * S;
-  for (int i = 0; i < H; ++i) {
-    float acc = b[i];
-    for (int j = 0; j < S; ++j) acc = acc + W[i * S + j] * obs[j];
-    h0[i] = serl_act(acc, d.activation);
+  const int lane = threadIdx.x & 63;
+  const int i0 = lane < H ? lane : H - 1, i1 = lane + 64 < H ? lane + 64 : H - 1;   // clamped row ids
+  const bool two = H > 64;
+  float h0a, h0b = 0.0f;
+  {
+    const float *W = w, *b = w + (size_t)H * S;
+    float acc0 = b[i0], acc1 = b[i1];
+    for (int j = 0; j < S; ++j) {
+      acc0 = acc0 + W[i0 * S + j] * obs[j];
+      if (two) acc1 = acc1 + W[i1 * S + j] * obs[j];
+    }
+    h0a = serl_act(acc0, d.activation);
+    if (two) h0b = serl_act(acc1, d.activation);
+    w = b + H;
   }
-  w = b + H;
   for (int l = 0; l < L; ++l) {
     const float *Wl = w, *bl = w + (size_t)H * H, *g = bl + H, *be = g + H;
-    for (int i = 0; i < H; ++i) {
-      float acc = bl[i];
-      for (int j = 0; j < H; ++j) acc = acc + Wl[i * H + j] * h0[j];
-      h1[i] = acc;
+    float acc0 = bl[i0], acc1 = bl[i1];
+    const float *r0 = Wl + (size_t)i0 * H, *r1 = Wl + (size_t)i1 * H;
+    for (int j = 0; j < H; ++j) {
+      const float hj = (j < 64) ? serl_bcast(h0a, j) : serl_bcast(h0b, j - 64);
+      acc0 = acc0 + r0[j] * hj;
+      if (two) acc1 = acc1 + r1[j] * hj;
     }
     float mean = 0.0f;
-    for (int i = 0; i < H; ++i) mean = mean + h1[i];
+    for (int i = 0; i < H; ++i) mean = mean + ((i < 64) ? serl_bcast(acc0, i) : serl_bcast(acc1, i - 64));
     mean = mean / (float)H;
+    const float d0 = acc0 - mean, d1 = acc1 - mean;
+    const float q0 = d0 * d0, q1 = d1 * d1;
     float var = 0.0f;
-    for (int i = 0; i < H; ++i) { float dl = h1[i] - mean; var = var + dl * dl; }
-    float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
-    for (int i = 0; i < H; ++i) h0[i] = serl_act(g[i] * (h1[i] - mean) / den + be[i], d.activation);
+    for (int i = 0; i < H; ++i) var = var + ((i < 64) ? serl_bcast(q0, i) : serl_bcast(q1, i - 64));
+    const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
+    h0a = serl_act(g[i0] * d0 / den + be[i0], d.activation);
+    if (two) h0b = serl_act(g[i1] * d1 / den + be[i1], d.activation);
     w = be + H;
   }
-  const float *Wo = w, *bo = w + (size_t)A * H;
-  for (int i = 0; i < A; ++i) {
-    float acc = bo[i];
-    for (int j = 0; j < H; ++j) acc = acc + Wo[i * H + j] * h0[j];
-    act_out[i] = tanhf(acc);
+  {
+    const float *Wo = w, *bo = w + (size_t)A * H;
+    const int io = lane < A ? lane : A - 1;
+    float acc = bo[io];
+    const float *ro_ = Wo + (size_t)io * H;
+    for (int j = 0; j < H; ++j) {
+      const float hj = (j < 64) ? serl_bcast(h0a, j) : serl_bcast(h0b, j - 64);
+      acc = acc + ro_[j] * hj;
+    }
+    const float t = tanhf(acc);
+    for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, i);
   }
 }
 
