@@ -51,6 +51,12 @@ class NetSpec:
         return H * S + H + L * (H * H + 3 * H) + A * H + A
 
     @property
+    def row_stride(self):
+        """floats per member row in the packed population tensor: param_count rounded up to a multiple of 4
+        (the kernel reads weight rows with 16-byte loads)"""
+        return (self.param_count + 3) // 4 * 4
+
+    @property
     def activation_id(self):
         return ACTIVATION_IDS[self.activation.lower()]
 
@@ -175,8 +181,14 @@ def pack_actor(actor_or_sd):
     return torch.cat([v.detach().reshape(-1).to(torch.float32).cpu() for v in sd.values()])
 
 
+def pad_rows(w):
+    """pad the parameter axis of a packed [M, P] tensor with zeros to a multiple of 4 floats"""
+    pad = (-w.shape[1]) % 4
+    return torch.nn.functional.pad(w, (0, pad)).contiguous() if pad else w.contiguous()
+
+
 def pack_population(actors, device=None):
-    w = torch.stack([pack_actor(a) for a in actors]).contiguous()
+    w = pad_rows(torch.stack([pack_actor(a) for a in actors]))
     return w.to(device) if device is not None else w
 
 

@@ -54,9 +54,13 @@ static __device__ void serl_actor_forward_wave(const serl_rollout_desc &d, const
   {
     const float *W = w, *b = w + (size_t)H * S;
     float acc0 = b[i0], acc1 = b[i1];
-    for (int j = 0; j < S; ++j) {
-      acc0 = acc0 + W[i0 * S + j] * obs[j];
-      if (two) acc1 = acc1 + W[i1 * S + j] * obs[j];
+    float wa[7], wb[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) { wa[j] = W[i0 * 7 + j]; wb[j] = two ? W[i1 * 7 + j] : 0.0f; }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      acc0 = acc0 + wa[j] * obs[j];
+      if (two) acc1 = acc1 + wb[j] * obs[j];
     }
     h0a = serl_act(acc0, d.activation);
     if (two) h0b = serl_act(acc1, d.activation);
@@ -66,10 +70,29 @@ static __device__ void serl_actor_forward_wave(const serl_rollout_desc &d, const
     const float *Wl = w, *bl = w + (size_t)H * H, *g = bl + H, *be = g + H;
     float acc0 = bl[i0], acc1 = bl[i1];
     const float *r0 = Wl + (size_t)i0 * H, *r1 = Wl + (size_t)i1 * H;
-    for (int j = 0; j < H; ++j) {
-      const float hj = (j < 64) ? serl_bcast(h0a, j) : serl_bcast(h0b, j - 64);
-      acc0 = acc0 + r0[j] * hj;
-      if (two) acc1 = acc1 + r1[j] * hj;
+    // rows are walked in chunks of 32 columns: the 8 (16) dwordx4 loads of a chunk are issued together so
+    // that one memory latency is paid per chunk, then the 32 multiply-adds run in index order
+    for (int jc = 0; jc < H; jc += 32) {
+      float wa[32], wb[32];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = jc + 4 * q;
+        const float4 v = (j + 3 < H) ? *(const float4 *)(r0 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wa[4 * q] = v.x; wa[4 * q + 1] = v.y; wa[4 * q + 2] = v.z; wa[4 * q + 3] = v.w;
+        if (two) {
+          const float4 u = (j + 3 < H) ? *(const float4 *)(r1 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+          wb[4 * q] = u.x; wb[4 * q + 1] = u.y; wb[4 * q + 2] = u.z; wb[4 * q + 3] = u.w;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int j = jc + q;
+        if (j < H) {
+          const float hj = (j < 64) ? serl_bcast(h0a, j & 63) : serl_bcast(h0b, j & 63);
+          acc0 = acc0 + wa[q] * hj;
+          if (two) acc1 = acc1 + wb[q] * hj;
+        }
+      }
     }
     float mean = 0.0f;
     for (int i = 0; i < H; ++i) mean = mean + ((i < 64) ? serl_bcast(acc0, i) : serl_bcast(acc1, i - 64));
@@ -88,9 +111,22 @@ static __device__ void serl_actor_forward_wave(const serl_rollout_desc &d, const
     const int io = lane < A ? lane : A - 1;
     float acc = bo[io];
     const float *ro_ = Wo + (size_t)io * H;
-    for (int j = 0; j < H; ++j) {
-      const float hj = (j < 64) ? serl_bcast(h0a, j) : serl_bcast(h0b, j - 64);
-      acc = acc + ro_[j] * hj;
+    for (int jc = 0; jc < H; jc += 32) {
+      float wa[32];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int j = jc + 4 * q;
+        const float4 v = (j + 3 < H) ? *(const float4 *)(ro_ + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wa[4 * q] = v.x; wa[4 * q + 1] = v.y; wa[4 * q + 2] = v.z; wa[4 * q + 3] = v.w;
+      }
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const int j = jc + q;
+        if (j < H) {
+          const float hj = (j < 64) ? serl_bcast(h0a, j & 63) : serl_bcast(h0b, j & 63);
+          acc = acc + wa[q] * hj;
+        }
+      }
     }
     const float t = tanhf(acc);
     for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, i);

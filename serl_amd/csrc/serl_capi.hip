@@ -119,6 +119,8 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     return fail(SERL_E_UNSUPPORTED, "serl_rollout: only the PH-LAB attitude task (state_dim 7, action_dim 3) is compiled in");
   if (d->hidden < 2 || d->hidden > SERL_MAX_HIDDEN || d->num_layers < 0 || d->num_layers > 16)
     return fail(SERL_E_UNSUPPORTED, "serl_rollout: hidden size / layer count out of range");
+  if (d->hidden % 4 != 0 || d->weight_stride % 4 != 0 || ((uintptr_t)d->weights & 15) != 0)
+    return fail(SERL_E_UNSUPPORTED, "serl_rollout: hidden size and weight_stride must be multiples of 4 and weights 16-byte aligned (dwordx4 row loads)");
   if (d->activation < 0 || d->activation > 2) return fail(SERL_E_INVALID, "serl_rollout: activation");
   if (d->weight_stride < serl_param_count(d->state_dim, d->hidden, d->num_layers, d->action_dim))
     return fail(SERL_E_INVALID, "serl_rollout: weight_stride smaller than the parameter count");

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _capi, builds, refsignals, metrics
-from .actor import NetSpec, pack_population, spec_of
+from .actor import NetSpec, pack_population, pad_rows, spec_of
 from .episode import Episode
 
 
@@ -86,7 +86,9 @@ class RolloutEngine:
         """Low-level: run len(member_of_episode) episodes.  weights f32 [M, >=P] (device or host),
         ref f64 [E, T, 3] or [T, 3] radians.  Returns dict of device tensors."""
         dev = self.device
-        w = torch.as_tensor(weights, dtype=torch.float32).to(dev).contiguous()
+        w = torch.as_tensor(weights, dtype=torch.float32).to(dev)
+        if w.shape[1] % 4 or w.stride(0) % 4 or not w.is_contiguous():
+            w = pad_rows(w)
         moe = torch.as_tensor(np.asarray(member_of_episode), dtype=torch.int32).to(dev).contiguous()
         E = moe.numel()
         ref_t = torch.as_tensor(ref, dtype=torch.float64).to(dev).contiguous()
