@@ -119,6 +119,10 @@ int serl_rollout(serl_ctx *ctx, const serl_rollout_desc *desc, void *stream);
 int serl_dyn_open_loop(serl_ctx *ctx, int slot, int32_t n_episodes, int32_t T, const double *cmds,
                        double *states, int32_t lanes_per_wave, void *stream);
 
+/* Development aid: with SERL_PROFILE=1 in the environment serl_rollout records shader-clock cycles of wave 0 of
+ * workgroup 0: out = {actor forward, dynamics step, env bookkeeping, env steps}. */
+int serl_debug_profile(serl_ctx *ctx, unsigned long long out[4]);
+
 /* Duration (ms) of the most recent serl_rollout kernel on its stream, measured with HIP events
  * recorded around the launch; blocks until that kernel has finished. */
 int serl_last_rollout_ms(serl_ctx *ctx, float *ms);

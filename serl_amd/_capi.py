@@ -9,7 +9,7 @@ VP = ctypes.c_void_p
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libserl_amd.so')
 
 EXPORTS = ['serl_abi_version', 'serl_last_error', 'serl_param_count', 'serl_ctx_create', 'serl_ctx_destroy',
-           'serl_ctx_load_build', 'serl_rollout', 'serl_dyn_open_loop', 'serl_last_rollout_ms', 'serl_ga_clone', 'serl_ga_crossover',
+           'serl_ctx_load_build', 'serl_rollout', 'serl_dyn_open_loop', 'serl_debug_profile', 'serl_last_rollout_ms', 'serl_ga_clone', 'serl_ga_crossover',
            'serl_ga_mutate', 'serl_ga_scaled_perturb']
 
 
@@ -54,6 +54,7 @@ def lib():
     L.serl_ctx_load_build.argtypes = [VP, ctypes.c_int, ctypes.POINTER(BuildDesc)]
     L.serl_rollout.argtypes = [VP, ctypes.POINTER(RolloutDesc), VP]
     L.serl_dyn_open_loop.argtypes = [VP, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, VP, VP, ctypes.c_int32, VP]
+    L.serl_debug_profile.argtypes = [VP, ctypes.POINTER(ctypes.c_ulonglong)]
     L.serl_last_rollout_ms.argtypes = [VP, ctypes.POINTER(ctypes.c_float)]
     L.serl_ga_clone.argtypes = [VP, VP, ctypes.c_int64, ctypes.c_int32, VP, VP, ctypes.c_int32, VP]
     L.serl_ga_crossover.argtypes = [VP, VP, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, VP, ctypes.c_int32, VP]

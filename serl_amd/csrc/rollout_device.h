@@ -18,6 +18,7 @@ struct RolloutArgs {
   double dyn_dt;
   int32_t lanes;                      // active lanes per 64-lane wavefront
   int32_t block;                      // threads per workgroup (64 x wavefronts sharing one LDS table copy)
+  unsigned long long *prof;           // optional [4] cycle counters of wave 0 / block 0: actor, dynamics, env, steps
 };
 
 static __device__ __forceinline__ float serl_act(float v, int act)
@@ -43,16 +44,62 @@ static __device__ __forceinline__ float serl_bcast(float v, int srclane)
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
 }
 
-static __device__ void serl_actor_forward_wave(const serl_rollout_desc &d, const float *__restrict__ w,
+typedef const __attribute__((address_space(1))) float *serl_gptr;   // weights live in global memory (HBM/L2)
+typedef float serl_v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) serl_v4f *serl_gptr4;
+
+// 32 consecutive weights of one row, as 8 dwordx4 loads issued together (zeros past column H)
+static __device__ __forceinline__ void serl_load_chunk(float (&wv)[32], serl_gptr row, int jc, int H)
+{
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    serl_v4f v = {0.f, 0.f, 0.f, 0.f};
+    if (jc + 4 * q < H) v = *(serl_gptr4)(row + jc + 4 * q);
+    wv[4 * q] = v.x; wv[4 * q + 1] = v.y; wv[4 * q + 2] = v.z; wv[4 * q + 3] = v.w;
+  }
+}
+
+// acc += sum_j w[j] * h[jc + j], j ascending, separate multiply and add; h[] is spread over the lanes of
+// hsrc (a 32-column chunk never straddles lane 63/64, so the source register is chunk-uniform)
+static __device__ __forceinline__ float serl_mac_chunk(float acc, const float (&wv)[32], float hsrc, int jb, int jc, int H)
+{
+  if (jc + 32 <= H) {
+#pragma unroll
+    for (int q = 0; q < 32; ++q) acc = acc + wv[q] * serl_bcast(hsrc, jb + q);
+  } else {
+#pragma unroll
+    for (int q4 = 0; q4 < 8; ++q4) {
+      if (jc + 4 * q4 < H) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) acc = acc + wv[4 * q4 + qq] * serl_bcast(hsrc, jb + 4 * q4 + qq);
+      }
+    }
+  }
+  return acc;
+}
+
+// sum of the first n row values in index order (every lane computes the same sum)
+static __device__ __forceinline__ float serl_seq_sum(float s, float v, int n)
+{
+#pragma unroll 8
+  for (int i = 0; i < n; ++i) s = s + serl_bcast(v, i);
+  return s;
+}
+
+static __device__ void serl_actor_forward_wave(const serl_rollout_desc &dd, const float *w_generic,
                                                const float obs[7], float act_out[3])
 {
-  const int S = d.state_dim, H = d.hidden, A = d.action_dim, L = d.num_layers;
+  // network shape is wave-uniform: pin it to SGPRs so that shape tests are scalar branches, not exec masks
+  const int H = __builtin_amdgcn_readfirstlane(dd.hidden), L = __builtin_amdgcn_readfirstlane(dd.num_layers);
+  const int act = __builtin_amdgcn_readfirstlane(dd.activation);
+  serl_gptr w = (serl_gptr)w_generic;
   const int lane = threadIdx.x & 63;
   const int i0 = lane < H ? lane : H - 1, i1 = lane + 64 < H ? lane + 64 : H - 1;   // clamped row ids
   const bool two = H > 64;
+  const int Ha = H < 64 ? H : 64, Hb = H - Ha;
   float h0a, h0b = 0.0f;
   {
-    const float *W = w, *b = w + (size_t)H * S;
+    serl_gptr W = w, b = w + (size_t)H * 7;
     float acc0 = b[i0], acc1 = b[i1];
     float wa[7], wb[7];
 #pragma unroll
@@ -62,71 +109,42 @@ static __device__ void serl_actor_forward_wave(const serl_rollout_desc &d, const
       acc0 = acc0 + wa[j] * obs[j];
       if (two) acc1 = acc1 + wb[j] * obs[j];
     }
-    h0a = serl_act(acc0, d.activation);
-    if (two) h0b = serl_act(acc1, d.activation);
+    h0a = serl_act(acc0, act);
+    if (two) h0b = serl_act(acc1, act);
     w = b + H;
   }
   for (int l = 0; l < L; ++l) {
-    const float *Wl = w, *bl = w + (size_t)H * H, *g = bl + H, *be = g + H;
+    serl_gptr Wl = w, bl = w + (size_t)H * H, g = bl + H, be = g + H;
     float acc0 = bl[i0], acc1 = bl[i1];
-    const float *r0 = Wl + (size_t)i0 * H, *r1 = Wl + (size_t)i1 * H;
-    // rows are walked in chunks of 32 columns: the 8 (16) dwordx4 loads of a chunk are issued together so
-    // that one memory latency is paid per chunk, then the 32 multiply-adds run in index order
+    serl_gptr r0 = Wl + (size_t)i0 * H, r1 = Wl + (size_t)i1 * H;
     for (int jc = 0; jc < H; jc += 32) {
       float wa[32], wb[32];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int j = jc + 4 * q;
-        const float4 v = (j + 3 < H) ? *(const float4 *)(r0 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-        wa[4 * q] = v.x; wa[4 * q + 1] = v.y; wa[4 * q + 2] = v.z; wa[4 * q + 3] = v.w;
-        if (two) {
-          const float4 u = (j + 3 < H) ? *(const float4 *)(r1 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-          wb[4 * q] = u.x; wb[4 * q + 1] = u.y; wb[4 * q + 2] = u.z; wb[4 * q + 3] = u.w;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 32; ++q) {
-        const int j = jc + q;
-        if (j < H) {
-          const float hj = (j < 64) ? serl_bcast(h0a, j & 63) : serl_bcast(h0b, j & 63);
-          acc0 = acc0 + wa[q] * hj;
-          if (two) acc1 = acc1 + wb[q] * hj;
-        }
-      }
+      serl_load_chunk(wa, r0, jc, H);
+      if (two) serl_load_chunk(wb, r1, jc, H);
+      const float hsrc = (jc < 64) ? h0a : h0b;
+      acc0 = serl_mac_chunk(acc0, wa, hsrc, jc & 63, jc, H);
+      if (two) acc1 = serl_mac_chunk(acc1, wb, hsrc, jc & 63, jc, H);
     }
-    float mean = 0.0f;
-    for (int i = 0; i < H; ++i) mean = mean + ((i < 64) ? serl_bcast(acc0, i) : serl_bcast(acc1, i - 64));
+    float mean = serl_seq_sum(0.0f, acc0, Ha);
+    if (two) mean = serl_seq_sum(mean, acc1, Hb);
     mean = mean / (float)H;
     const float d0 = acc0 - mean, d1 = acc1 - mean;
-    const float q0 = d0 * d0, q1 = d1 * d1;
-    float var = 0.0f;
-    for (int i = 0; i < H; ++i) var = var + ((i < 64) ? serl_bcast(q0, i) : serl_bcast(q1, i - 64));
+    float var = serl_seq_sum(0.0f, d0 * d0, Ha);
+    if (two) var = serl_seq_sum(var, d1 * d1, Hb);
     const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
-    h0a = serl_act(g[i0] * d0 / den + be[i0], d.activation);
-    if (two) h0b = serl_act(g[i1] * d1 / den + be[i1], d.activation);
+    h0a = serl_act(g[i0] * d0 / den + be[i0], act);
+    if (two) h0b = serl_act(g[i1] * d1 / den + be[i1], act);
     w = be + H;
   }
   {
-    const float *Wo = w, *bo = w + (size_t)A * H;
-    const int io = lane < A ? lane : A - 1;
+    serl_gptr Wo = w, bo = w + (size_t)3 * H;
+    const int io = lane < 3 ? lane : 2;
     float acc = bo[io];
-    const float *ro_ = Wo + (size_t)io * H;
+    serl_gptr ro_ = Wo + (size_t)io * H;
     for (int jc = 0; jc < H; jc += 32) {
       float wa[32];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int j = jc + 4 * q;
-        const float4 v = (j + 3 < H) ? *(const float4 *)(ro_ + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-        wa[4 * q] = v.x; wa[4 * q + 1] = v.y; wa[4 * q + 2] = v.z; wa[4 * q + 3] = v.w;
-      }
-#pragma unroll
-      for (int q = 0; q < 32; ++q) {
-        const int j = jc + q;
-        if (j < H) {
-          const float hj = (j < 64) ? serl_bcast(h0a, j & 63) : serl_bcast(h0b, j & 63);
-          acc = acc + wa[q] * hj;
-        }
-      }
+      serl_load_chunk(wa, ro_, jc, H);
+      acc = serl_mac_chunk(acc, wa, (jc < 64) ? h0a : h0b, jc & 63, jc, H);
     }
     const float t = tanhf(acc);
     for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, i);

@@ -34,6 +34,7 @@ struct serl_ctx {
   BuildSlot slots[SERL_MAX_SLOTS];
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
+  unsigned long long *prof = nullptr;   // device [4], allocated when SERL_PROFILE=1
 };
 
 void serl_launch_rollout_nominal(const RolloutArgs &a, int grid, hipStream_t stream);
@@ -129,9 +130,16 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   const BuildSlot &s = c->slots[d->build_slot];
   hipStream_t stream = (hipStream_t)stream_;
   RolloutArgs a;
+  memset(&a, 0, sizeof(a));
   a.d = *d;
   a.ro = s.blob; a.t3 = s.blob + s.n_ro; a.x0 = a.t3 + 46; a.dw0 = a.x0 + 19;
   a.dyn_dt = s.dt;
+  a.prof = nullptr;
+  if (getenv("SERL_PROFILE")) {
+    if (!c->prof) HIP_TRY(hipMalloc((void **)&c->prof, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(c->prof, 0, 4 * sizeof(unsigned long long), stream));
+    a.prof = c->prof;
+  }
   int lanes = d->lanes_per_wave;
   if (lanes <= 0) {
     // latency-bound regime: spread episodes over wavefronts until every SIMD of the chip has one
@@ -180,6 +188,16 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, stream));
   c->timed = true;
+  return SERL_OK;
+}
+
+/* development aid (SERL_PROFILE=1): shader-clock cycles wave 0 of workgroup 0 spent in the actor forward, the
+ * dynamics step and the env bookkeeping during the last serl_rollout, and its number of env steps */
+int serl_debug_profile(serl_ctx *c, unsigned long long out[4])
+{
+  if (!c || !out || !c->prof) return fail(SERL_E_INVALID, "serl_debug_profile: profiling not enabled (SERL_PROFILE=1)");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, c->prof, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return SERL_OK;
 }
 

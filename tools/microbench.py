@@ -25,5 +25,11 @@ for E, lanes in [(1, 1), (150, 1), (150, 64), (4096, 64)]:
     out = eng.rollout(w, spec, moe, ref, t_max=4, lanes_per_wave=lanes)
     ms = eng.last_kernel_ms
     res['loop_E%d_L%d' % (E, lanes)] = dict(ms=ms, us_per_step=ms * 1e3 / n, steps_per_s=E * n / (ms * 1e-3))
+    if os.environ.get('SERL_PROFILE'):
+        import ctypes
+        buf = (ctypes.c_ulonglong * 4)()
+        eng.lib.serl_debug_profile(eng.ctx, buf)
+        st = max(buf[3], 1)
+        res['loop_E%d_L%d' % (E, lanes)]['cycles_per_step'] = dict(actor=buf[0] / st, dyn=buf[1] / st, env=buf[2] / st)
 for k, v in res.items():
     print(k, json.dumps(v))
