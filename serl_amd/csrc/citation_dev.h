@@ -38,6 +38,7 @@ struct CitCtx {
   const double *ro;      // unused on the device (tables are staged in LDS: g_ro)
   const double *t3;      // table3 parameters P1[3] P2[4] P3[3] P4[36]
   CitAxes ax;            // trigonometry + rotation matrices of the current model evaluation
+  int32_t bslot;         // first word of this episode's window in g_B (LDS flavour)
   int32_t err;           // CIT_ERR_* flags
 };
 
@@ -59,7 +60,16 @@ static __device__ __forceinline__ uint64_t d2u(double d) { return (uint64_t)__do
 static __device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long)u); }
 
 #define RO_D(o)    (g_ro[((uint64_t)(o) >> 3) - CIT_RO_LO_W])
-#define B_D(o)     (c->B[(uint64_t)(o) >> 3])
+// Block signals B (647 f64 per model instance) have two homes, chosen per kernel flavour (CIT_B_LDS):
+//   registers  -- B is a function-local array of the step function, promoted to SSA values; what does not fit
+//                 the 512-register budget spills to scratch.  Only choice when a wavefront carries many episodes.
+//   LDS        -- one 5 KiB window per episode; used when a wavefront carries <= SERL_LDS_B_LANES_PER_WAVE
+//                 episodes (the latency-bound regime): an LDS access costs ~64 cycles where a scratch spill
+//                 costs a trip through the vector memory path.
+#define SERL_LDS_B_LANES_PER_WAVE 2
+#define SERL_LDS_B_SLOTS (4 * SERL_LDS_B_LANES_PER_WAVE)
+__shared__ double g_B[SERL_LDS_B_SLOTS * CIT_MAX_NB];
+#define B_D(o)     CIT_B_AT((uint64_t)(o) >> 3)
 #define X_D(o)     (c->X[(uint64_t)(o) >> 3])
 #define DW_D(o)    (c->DW[(uint64_t)(o) >> 3])
 #define Y_D(o)     (c->Y[(uint64_t)(o) >> 3])
@@ -170,7 +180,6 @@ static __device__ inline void cit_reset(CitCtx *c, const double *ro, const doubl
                                         const double *dw0, double dt)
 {
   for (int i = 0; i < 19; ++i) c->X[i] = x0[i];
-  for (int i = 0; i < CIT_MAX_NB; ++i) c->B[i] = 0.0;
   for (int i = 0; i < 29; ++i) c->DW[i] = dw0[i];
   const int32_t *iw = (const int32_t *)(dw0 + 29);
   c->IW[0] = iw[0]; c->IW[1] = iw[1]; c->IW[2] = iw[2]; c->IW[3] = 0;

@@ -20,7 +20,7 @@ static __device__ __noinline__ void CIT_STEP(CitCtx *gc, const double *cmd_in, d
   for (int i = 0; i < 12; ++i) lc.Y[i] = gc->Y[i];
   for (int i = 0; i < 10; ++i) cmd[i] = cmd_in[i];
   lc.t = gc->t; lc.stop_time = gc->stop_time; lc.dt = gc->dt; lc.tick = gc->tick;
-  lc.ro = gc->ro; lc.t3 = gc->t3; lc.err = gc->err;
+  lc.ro = gc->ro; lc.t3 = gc->t3; lc.err = gc->err; lc.bslot = gc->bslot;
   const double t0 = lc.t, h = lc.dt;
   for (int s = 0; s < 6; ++s) {
     if (s > 0) {

@@ -142,9 +142,10 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   }
   int lanes = d->lanes_per_wave;
   if (lanes <= 0) {
-    // latency-bound regime: spread episodes over wavefronts until every SIMD of the chip has one
-    // (256 CUs x 4 SIMDs), then start packing lanes
-    lanes = (d->n_episodes + 1023) / 1024;
+    // A wavefront takes the same time per env step whether it carries 1 or 64 episodes, and wavefronts that
+    // share a CU slow each other down (measured: profiles/r01_microbench.md), so episodes are spread one
+    // wavefront per CU first (256 CUs) and only then packed into lanes.
+    lanes = (d->n_episodes + 255) / 256;
     if (lanes < 1) lanes = 1;
   }
   if (lanes > 64) lanes = 64;
@@ -174,7 +175,7 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
   a.d.n_episodes = n_episodes;
   a.ro = s.blob; a.t3 = s.blob + s.n_ro; a.x0 = a.t3 + 46; a.dw0 = a.x0 + 19;
   a.dyn_dt = s.dt;
-  int lanes = lanes_per_wave <= 0 ? (n_episodes + 1023) / 1024 : lanes_per_wave;
+  int lanes = lanes_per_wave <= 0 ? (n_episodes + 255) / 256 : lanes_per_wave;
   if (lanes > 64) lanes = 64;
   a.lanes = lanes;
   const int nwaves = (n_episodes + lanes - 1) / lanes;
