@@ -1,0 +1,169 @@
+"""The oracle's episode / GA-evaluate restatement (oracle/rollout_ref.c) pinned against golden vectors that the
+REFERENCE'S OWN Python produced (tests/golden/make_golden.py: unmodified Agent.evaluate + CitationEnv + Actor +
+the reference shared object) and against the trajectories the reference ships in logs/wandb.
+
+Tolerances: episode lengths / termination step / ranking indices exact; episodic return 1e-5 relative (the only
+difference is the f32 summation order of the actor: torch's CPU GEMV vs the sequential restatement).
+"""
+import numpy as np
+import pytest
+
+NET = {'serl50': dict(state_dim=7, action_dim=3, hidden=32, num_layers=3, activation='tanh'),
+       'serl10': dict(state_dim=7, action_dim=3, hidden=72, num_layers=3, activation='tanh'),
+       'td3': dict(state_dim=7, action_dim=3, hidden=96, num_layers=3, activation='relu')}
+RTOL = 1e-5
+
+
+@pytest.mark.parametrize('tag', ['serl50', 'serl10', 'td3'])
+def test_population_fitness_vs_reference_python(golden, tag):
+    from oracle import rollout as R
+    g = golden('pop_' + tag if tag != 'td3' else 'td3')
+    w = golden('actors')[tag]
+    ref = golden('ref_base')['ref']
+    o = R.rollout(w, NET[tag], np.arange(len(w)), ref, t_max=80, threads=8)
+    np.testing.assert_allclose(o['fitness'], g['fitness'], rtol=RTOL)
+    np.testing.assert_array_equal(o['length_t'], g['length'])
+    assert (o['length_steps'] == 8001).all()
+    np.testing.assert_array_equal(np.argsort(o['fitness']), np.argsort(g['fitness']))
+    assert int(np.argmax(o['fitness'])) == int(np.argmax(g['fitness']))
+
+
+def test_known_answers_from_the_survey(golden):
+    """sum of rewards over all 8 001 steps, base reference, nominal build."""
+    from oracle import rollout as R
+    w = golden('actors')['serl50'][[18, 0, 7]]
+    o = R.rollout(w, NET['serl50'], [0, 1, 2], golden('ref_base')['ref'], t_max=80)
+    np.testing.assert_allclose(o['fitness'], [-82.3058562477, -116.4606332304, -117.5455179587], rtol=RTOL)
+
+
+@pytest.mark.parametrize('tag,idx', [('serl50', 18), ('serl10', 0), ('td3', 0)])
+def test_trajectory_vs_reference_python(golden, tag, idx):
+    from oracle import rollout as R
+    from oracle.smoothness import calc_smoothness
+    t = golden('traj')
+    w = golden('actors')[tag][[idx]]
+    o = R.rollout(w, NET[tag], [0], golden('ref_base')['ref'], t_max=80, traces=True)
+    np.testing.assert_allclose(o['actions'][0], t['%s_%d_actions' % (tag, idx)], atol=2e-6)
+    np.testing.assert_allclose(o['rewards'][0], t['%s_%d_rewards' % (tag, idx)], atol=2e-5)
+    np.testing.assert_allclose(o['states'][0][::25], t['%s_%d_states25' % (tag, idx)], rtol=2e-4, atol=2e-5)
+    g = golden('pop_' + tag if tag != 'td3' else 'td3')
+    np.testing.assert_allclose(calc_smoothness(o['actions'][0]), g['smoothness'][idx], rtol=1e-4)
+
+
+@pytest.mark.parametrize('tag', ['serl50', 'td3'])
+def test_shipped_closed_loop_trajectories(golden, tag):
+    """logs/wandb/*/figures/nominal/nominal_trajectory.csv (de-filtered): what the authors' machine produced with
+    torch 1.10 -- return to 1e-6 relative, states/actions to plotting accuracy."""
+    from oracle import rollout as R
+    s = golden('shipped_csv')
+    w = golden('actors')[tag][[18 if tag == 'serl50' else 0]]
+    ref = golden('ref_base')['ref']
+    np.testing.assert_allclose(ref[::25], s[tag + '_ref'], atol=2e-15)
+    o = R.rollout(w, NET[tag], [0], ref, t_max=80, traces=True)
+    n = int(s[tag + '_n'])
+    assert n == 8001
+    # the shipped file logs the reward of step k in row k+1 and misses the terminal one: compare the common part
+    ours = o['rewards'][0]
+    shipped = s[tag + '_reward']
+    np.testing.assert_allclose(ours[:n - 1].sum(), shipped[1:n].sum(), rtol=1e-6)
+    np.testing.assert_allclose(o['states'][0][::25][:-1], s[tag + '_x'][1:], rtol=1e-3, atol=1e-4)
+
+
+def test_faults_and_trims_vs_reference_python(golden):
+    from oracle import rollout as R
+    from serl_amd import builds
+    g = golden('faults')
+    w = golden('actors')['serl50'][[18, 0, 7]]
+    ref = golden('ref_base')['ref']
+    for mode in ['be', 'jr', 'sa', 'se', 'ice', 'cg', 'cg-for', 'high-q', 'low-q', 'cg-shift', 'gust']:
+        build, row = builds.resolve_mode(mode)
+        o = R.rollout(w, NET['serl50'], [0, 1, 2], ref, build=build, faults=[row] * 3, t_max=80, threads=3)
+        for j, i in enumerate((18, 0, 7)):
+            ref_fit, ref_len, ref_sm, ref_n = g['%s_%d' % (mode, i)]
+            assert o['length_steps'][j] == int(ref_n), (mode, i)
+            assert o['length_t'][j] == ref_len, (mode, i)
+            np.testing.assert_allclose(o['fitness'][j], ref_fit, rtol=RTOL, err_msg='%s %d' % (mode, i))
+
+
+def test_error_carried_into_next_episode(golden):
+    """envs/phlabenv.py:401-428 never clears self.error: obs0 of an episode carries the previous episode's last
+    tracking error when the same env object is reused (the sequential reference loop)."""
+    from oracle import rollout as R
+    from serl_amd import refsignals
+    c = golden('carry')
+    w = golden('actors')['serl50'][[18, 0, 7]]
+    ref = refsignals.tabulate(*refsignals.base_reference(20), 20)
+    o = R.rollout(w, NET['serl50'], [0, 1, 2], ref, err0=c['err0'], t_max=20, traces=True)
+    np.testing.assert_allclose(o['fitness'], c['fitness'], rtol=RTOL)
+    np.testing.assert_array_equal(o['length_t'], c['length'])
+    # and the carried value IS the last error of the previous episode
+    for j in (0, 1):
+        n = o['length_steps'][j]
+        np.testing.assert_allclose(ref[n - 1] - o['states'][j][n - 1][[7, 6, 5]], c['err0'][j + 1], atol=1e-6)
+
+
+def test_actor_forward_samples_vs_torch_reference(golden):
+    """The f32 MLP (custom LayerNorm: unbiased std, eps on std; 'relu' = LeakyReLU) against the reference's
+    torch Actor on 64 random observations for every shipped actor -- via a 1-step open rollout is not possible,
+    so the numpy restatement below mirrors oracle/rollout_ref.c:actor_forward and is itself checked end-to-end
+    by the population tests above."""
+    for tag in ('serl50', 'serl10', 'td3'):
+        g = golden('pop_' + tag if tag != 'td3' else 'td3')
+        w = golden('actors')[tag]
+        net = NET[tag]
+        H, L = net['hidden'], net['num_layers']
+        obs = g['obs_samples'].astype(np.float32)
+        for m in range(len(w)):
+            p = w[m]; off = 0
+
+            def take(n, shape):
+                nonlocal off
+                v = p[off:off + n].reshape(shape); off += n
+                return v
+            act = {'tanh': np.tanh, 'relu': lambda v: np.where(v > 0, v, np.float32(0.01) * v)}[net['activation']]
+            h = act(obs @ take(H * 7, (H, 7)).T + take(H, (H,)))
+            for _ in range(L):
+                z = h @ take(H * H, (H, H)).T + take(H, (H,))
+                gm, bt = take(H, (H,)), take(H, (H,))
+                mean = z.mean(-1, keepdims=True)
+                std = z.std(-1, ddof=1, keepdims=True)
+                h = act(gm * (z - mean) / (std + np.float32(1e-6)) + bt)
+            a = np.tanh(h @ take(3 * H, (3, H)).T + take(3, (3,)))
+            np.testing.assert_allclose(a, g['act_samples'][m], atol=3e-6)
+
+
+def test_early_termination_penalty_and_length():
+    """Diverging actors: done at the first step out of bounds, penalty -(1/dt)*(t_max - t)*2 added to the last
+    reward (envs/phlabenv.py:391-399)."""
+    from oracle import rollout as R
+    from serl_amd import refsignals
+    rng = np.random.default_rng(3)
+    w = rng.normal(0, 0.3, (6, 3715)).astype(np.float32)
+    ref = refsignals.tabulate(*refsignals.base_reference(20), 20)
+    o = R.rollout(w, NET['serl50'], np.arange(6), ref, t_max=20, traces=True)
+    early = o['length_steps'] < 2001
+    assert early.any()
+    for e in np.nonzero(early)[0]:
+        n = o['length_steps'][e]
+        x = o['states'][e][n - 1]
+        assert abs(x[7]) > np.deg2rad(60) or abs(x[6]) > np.deg2rad(75) or x[9] < 50
+        t_last = refsignals.env_times(n)[-1]
+        pen = -1.0 / 0.01 * (20.0 - t_last) * 2.0
+        assert o['rewards'][e][n - 1] < pen + 1e-9 and o['rewards'][e][n - 1] >= pen - 1.0
+        np.testing.assert_allclose(o['fitness'][e], o['rewards'][e][:n].sum(), rtol=1e-12)
+
+
+def test_action_noise_path_and_table_exhaustion():
+    from oracle import rollout as R
+    from serl_amd import refsignals
+    w = np.load(__import__('os').path.join(__import__('os').path.dirname(__file__), 'golden', 'actors.npz'))['serl50'][[18]]
+    ref = refsignals.tabulate(*refsignals.base_reference(20), 20)
+    rng = np.random.default_rng(0)
+    noise = np.clip(0.2 * rng.standard_normal((1, len(ref), 3)), -0.5, 0.5)
+    a = R.rollout(w, NET['serl50'], [0], ref, t_max=20)
+    b = R.rollout(w, NET['serl50'], [0], ref, t_max=20, action_noise=noise)
+    c = R.rollout(w, NET['serl50'], [0], ref, t_max=20, action_noise=np.zeros_like(noise))
+    assert b['fitness'][0] != a['fitness'][0]
+    np.testing.assert_allclose(c['fitness'], a['fitness'], rtol=1e-6)   # f64 vs f32 scaling of the same action
+    with pytest.raises(RuntimeError):
+        R.rollout(w, NET['serl50'], [0], ref[:100], t_max=20)
