@@ -89,3 +89,23 @@ int cit_step_n(CitInstance *I, const double *cmd, double *out, int n)
 double *cit_B(CitInstance *I) { return I->c.B; }
 double *cit_X(CitInstance *I) { return I->c.X; }
 double *cit_DW(CitInstance *I) { return I->c.DW; }
+
+/* One model evaluation at a caller-supplied state (test aid for tools/dag: per-stage comparison of the block
+ * signals B and the derivative vector).  major != 0 also latches rtY and updates the Derivative-block banks. */
+int cit_eval(CitInstance *I, const double *X, const double *cmd, double t, int major, double *xdot)
+{
+  CitCtx *c = &I->c;
+  double out[12];
+  memcpy(c->X, X, sizeof(c->X));
+  c->t = t; c->major = major;
+  switch (I->code) {
+    case CIT_CODE_NOMINAL: cit_nominal_model(c, cmd, out); cit_nominal_derivatives(c, xdot); break;
+    case CIT_CODE_ICE: cit_ice_model(c, cmd, out); cit_ice_derivatives(c, xdot); break;
+    case CIT_CODE_CG_TIMED: cit_cg_timed_model(c, cmd, out); cit_cg_timed_derivatives(c, xdot); break;
+    case CIT_CODE_GUST: cit_gust_model(c, cmd, out); cit_gust_derivatives(c, xdot); break;
+    case CIT_CODE_TEST: cit_test_model(c, cmd, out); cit_test_derivatives(c, xdot); break;
+    default: return -1;
+  }
+  c->major = 1;
+  return 0;
+}

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libserl_amd.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-UNITS = ['serl_capi.hip', 'rollout_nominal.hip', 'rollout_ice.hip']
+UNITS = ['serl_capi.hip', 'rollout_nominal.hip', 'rollout_ice.hip', 'rollout_wave_nominal.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-Wno-unused-value']
 
 

@@ -1,0 +1,162 @@
+// citation_wave.h -- runtime of the wave-cooperative Citation model evaluation (product code, gfx950).
+//
+// One wavefront owns one episode.  The generated evaluation function (gen/citation_<variant>_wave.inc, produced
+// by tools/dag from the lifted model) computes the scalar "glue" of one model evaluation wave-uniformly and hands
+// the table look-ups -- the bulk of the reference's work (61 rt_Lookup2D_Normal +
+// 22 rt_Lookup + 144 rt_GetLookupIndex binary searches per evaluation) -- to the 64 lanes:
+//
+//   citw_search     one lane per distinct (breakpoint vector, input): rt_GetLookupIndex @0xf470 restated as a
+//                   branch-free count (the vectors are strictly increasing, <= 22 entries)
+//   citw_lookup2d   one lane per 2-D table: rt_Lookup2D_Normal @0xf590 (column-major z[ix + nx*iy],
+//                   interpolate along x on both columns, then along y; operation order of the binary)
+//   citw_lookup1d   one lane per 1-D table: rt_Lookup @0xf530   (y1-y0)/(x1-x0)*(u-x0)+y0
+//   citw_table3     the `table3` S-function (mdlOutputs @0x10da0, Table2 @0x10a30), wave-uniform
+//
+// Inputs and results travel over a per-wave LDS blackboard (CitwWave); the model tables sit in LDS once per
+// workgroup (g_ro, 94 KiB).  Within a wavefront LDS operations complete in order, so no barrier is needed
+// between the phases.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CITW_MAX_ROUNDS 3
+#define CITW_RO_LDS_WORDS 12040
+
+struct CitwSearch { uint16_t xw, n, in, pad; };                                 // 8 B
+struct CitwLookup { uint16_t xrw, nr, xcw, zw, sx, sy, in0, in1, out, p0, p1, p2; };   // 24 B; 1-D: x = xrw, y = zw
+
+struct CitwWave {                     // per-wavefront LDS scratch
+  double in[32];                      // look-up inputs of the current round
+  double out[CITW_MAX_ROUNDS][128];   // look-up results: [round][0..63] 2-D pass, [64..127] 1-D pass
+  int sidx[64];                       // interval indices of the current round
+  double DW[32];                      // Derivative-block banks (rtDW): TimeStampA, LastUAtTimeA[12], TimeStampB, LastUAtTimeB[12]
+  double f[6][20];                    // ODE5 stage derivatives
+  double xs[20];                      // stage state exchange (lane i <-> wave-uniform)
+};
+
+__shared__ double g_ro[CITW_RO_LDS_WORDS];
+__shared__ double g_t3[48];
+__shared__ CitwSearch g_S[CITW_MAX_ROUNDS][64];
+__shared__ CitwLookup g_L[CITW_MAX_ROUNDS][2][64];
+
+static __device__ __forceinline__ unsigned long long citw_d2u(double d) { return (unsigned long long)__double_as_longlong(d); }
+static __device__ __forceinline__ double citw_u2d(unsigned long long u) { return __longlong_as_double((long long)u); }
+
+// interval index (rt_GetLookupIndex semantics):
+//   u <= x[0] -> 0 ; u >= x[n-1] -> n-2 ; u < 0: x[i] <= u < x[i+1] ; u >= 0: x[i] < u <= x[i+1]
+template <int MAXN>
+static __device__ __forceinline__ void citw_search(CitwWave &w, const CitwSearch *S, int lane)
+{
+  const CitwSearch d = S[lane];
+  const double u = w.in[d.in];
+  const double *x = g_ro + d.xw;
+  const int n = d.n;
+  int lt = 0, le = 0;
+#pragma unroll
+  for (int i = 0; i < MAXN; ++i) {
+    const double v = x[i < n ? i : 0];
+    const bool ok = i < n;
+    lt += (ok && v < u) ? 1 : 0;
+    le += (ok && v <= u) ? 1 : 0;
+  }
+  int idx = ((u < 0.0) ? le : lt) - 1;
+  idx = idx < 0 ? 0 : idx;
+  idx = idx > n - 2 ? n - 2 : idx;
+  w.sidx[lane] = idx;
+}
+
+static __device__ __forceinline__ void citw_lookup2d(CitwWave &w, const CitwLookup *L, double *out, int lane)
+{
+  const CitwLookup d = L[lane];
+  const int ix = w.sidx[d.sx], iy = w.sidx[d.sy];
+  const double u0 = w.in[d.in0], u1 = w.in[d.in1];
+  const double *xr = g_ro + d.xrw, *xc = g_ro + d.xcw, *z = g_ro + d.zw;
+  const int nr = d.nr;
+  const double x0 = xr[ix], x1 = xr[ix + 1];
+  const double dx = x1 - x0, wx = u0 - x0;
+  const double z00 = z[ix + nr * iy], z10 = z[ix + 1 + nr * iy];
+  const double z01 = z[ix + nr * (iy + 1)], z11 = z[ix + 1 + nr * (iy + 1)];
+  double a = z10 - z00; a = a / dx; a = a * wx; a = a + z00;
+  double b = z11 - z01; b = b / dx; b = b * wx; b = b + z01;
+  const double y0 = xc[iy];
+  const double dy = xc[iy + 1] - y0;
+  double r = b - a; r = r / dy; r = r * (u1 - y0);
+  out[d.out] = r + a;
+}
+
+static __device__ __forceinline__ void citw_lookup1d(CitwWave &w, const CitwLookup *L, double *out, int lane)
+{
+  const CitwLookup d = L[lane];
+  const int i = w.sidx[d.sx];
+  const double u = w.in[d.in0];
+  const double *x = g_ro + d.xrw, *y = g_ro + d.zw;
+  const double x0 = x[i], x1 = x[i + 1], y0 = y[i], y1 = y[i + 1];
+  double r = y1 - y0;
+  r = r / (x1 - x0);
+  r = r * (u - x0);
+  out[d.out] = r + y0;
+}
+
+// ---- table3 S-function: 3-D table, linear interpolation.  The reference walks linearly from an interval cached in
+// IWORK/RWORK (part of rtDW, not observable through step()); the interval it ends on is
+// clamp(max{i : tab[i] < x}, 0, n-2) whatever the cache holds.
+static __device__ __forceinline__ int citw_t3_interval(const double *tab, int n, double x)
+{
+  int i = -1;
+  for (int k = 0; k < n; ++k) i = (tab[k] < x) ? k : i;
+  i = i < 0 ? 0 : i;
+  return i > n - 2 ? n - 2 : i;
+}
+
+static __device__ __forceinline__ double citw_table2(const double *xt, const double *yt, int ix, int iy, const double *tab,
+                                                     int M, double x, double y)
+{
+  double rows[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const double v0 = tab[(ix + 0) * M + (iy + j)], v1 = tab[(ix + 1) * M + (iy + j)];
+    const double x1 = xt[ix + 1], x0 = xt[ix];
+    double d = v1 - v0; const double dx = x1 - x0, wgt = x - x0;
+    d = d * wgt; d = d / dx;
+    rows[j] = (x == x1) ? v1 : d + v0;
+  }
+  const double y1 = yt[iy + 1], y0 = yt[iy];
+  const double wgt = y - y0, dy = y1 - y0;
+  double d = rows[1] - rows[0];
+  d = d * wgt; d = d / dy;
+  return (y == y1) ? rows[1] : d + rows[0];
+}
+
+static __device__ __noinline__ double citw_table3(const double *t3, double u0, double u1, double u2)
+{
+  const double *P1 = t3, *P2 = t3 + 3, *P3 = t3 + 7, *P4 = t3 + 10;
+  const int i0 = citw_t3_interval(P1, 3, u0), i1 = citw_t3_interval(P2, 4, u1), i2 = citw_t3_interval(P3, 3, u2);
+  const double *slab = P4 + i2 * 12;
+  const double a = citw_table2(P1, P2, i0, i1, slab, 4, u0, u1);
+  const double b = citw_table2(P1, P2, i0, i1, slab + 12, 4, u0, u1);
+  const double z1 = P3[i2 + 1], z0 = P3[i2];
+  const double wgt = u2 - z0, dz = z1 - z0;
+  double d = b - a;
+  d = d * wgt; d = d / dz;
+  return (u2 == z1) ? b : d + a;
+}
+
+// Dormand-Prince "ode5" tableau as the reference's literal pool holds it (0x13688, 0x13898..0x13938)
+__device__ static const double citw_ode5_A[6] = {0.2, 0.3, 0.8, 0.8888888888888888, 1.0, 1.0};
+__device__ static const double citw_ode5_B[6][6] = {
+  {0.2, 0, 0, 0, 0, 0},
+  {0.075, 0.225, 0, 0, 0, 0},
+  {0.9777777777777777, -3.7333333333333334, 3.5555555555555554, 0, 0, 0},
+  {2.9525986892242035, -11.595793324188385, 9.822892851699436, -0.2908093278463649, 0, 0},
+  {2.8462752525252526, -10.757575757575758, 8.906422717743473, 0.2784090909090909, -0.2735313036020583, 0},
+  {0.09114583333333333, 0.0, 0.44923629829290207, 0.6510416666666666, -0.322376179245283, 0.13095238095238096},
+};
+
+// Per-episode dynamics state of the wave kernel: the 19 continuous states are wave-uniform (every lane holds the
+// same value); lane i < 19 additionally keeps state i privately for the lane-parallel ODE5 combination.
+struct CitwState {
+  double X[19];
+  double xi;          // this lane's own state component (lane < 19)
+  double t;           // model time
+  unsigned tick;      // clockTick0
+};

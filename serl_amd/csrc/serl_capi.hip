@@ -41,6 +41,21 @@ void serl_launch_rollout_nominal(const RolloutArgs &a, int grid, hipStream_t str
 void serl_launch_rollout_ice(const RolloutArgs &a, int grid, hipStream_t stream);
 void serl_launch_dyn_nominal(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
 void serl_launch_dyn_ice(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
+void serl_launch_rollout_wave_nominal(const RolloutArgs &a, int grid, hipStream_t stream);
+void serl_launch_dyn_wave_nominal(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
+
+// The wave-cooperative kernels (one wavefront per episode, rollout_wave.inc) exist for these code variants.
+static bool serl_has_wave_kernel(int code) { return code == SERL_DYN_NOMINAL; }
+
+// Wavefronts per workgroup of the wave-cooperative kernels: one per CU while there are no more episodes than CUs,
+// then up to four (one per SIMD) sharing the workgroup's LDS copy of the tables.
+static int serl_wave_kernel_waves_per_block(int episodes)
+{
+  const char *env = getenv("SERL_WAVES_PER_BLOCK");
+  if (env && atoi(env) >= 1 && atoi(env) <= 4) return atoi(env);
+  int w = (episodes + 255) / 256;
+  return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
 
 // Wavefronts per workgroup.  One workgroup stages one LDS copy of the tables (94 KiB of the CU's 160 KiB), so
 // only one workgroup fits a CU: while there are no more wavefronts than CUs each gets a CU of its own (the
@@ -141,6 +156,19 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     a.prof = c->prof;
   }
   int lanes = d->lanes_per_wave;
+  if (lanes <= 0 && serl_has_wave_kernel(s.code)) {
+    // default: one wavefront per episode (model glue wave-uniform, look-ups / actor rows / ODE5 states per lane)
+    const int wpb = serl_wave_kernel_waves_per_block(d->n_episodes);
+    a.lanes = 1;
+    a.block = 64 * wpb;
+    const int grid = (d->n_episodes + wpb - 1) / wpb;
+    HIP_TRY(hipEventRecord(c->ev0, stream));
+    serl_launch_rollout_wave_nominal(a, grid, stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, stream));
+    c->timed = true;
+    return SERL_OK;
+  }
   if (lanes <= 0) {
     // A wavefront takes the same time per env step whether it carries 1 or 64 episodes, and wavefronts that
     // share a CU slow each other down (measured: profiles/r01_microbench.md), so episodes are spread one
@@ -175,6 +203,18 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
   a.d.n_episodes = n_episodes;
   a.ro = s.blob; a.t3 = s.blob + s.n_ro; a.x0 = a.t3 + 46; a.dw0 = a.x0 + 19;
   a.dyn_dt = s.dt;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (lanes_per_wave <= 0 && serl_has_wave_kernel(s.code)) {
+    const int wpb = serl_wave_kernel_waves_per_block(n_episodes);
+    a.lanes = 1;
+    a.block = 64 * wpb;
+    HIP_TRY(hipEventRecord(c->ev0, stream));
+    serl_launch_dyn_wave_nominal(a, cmds, states, T, (n_episodes + wpb - 1) / wpb, stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, stream));
+    c->timed = true;
+    return SERL_OK;
+  }
   int lanes = lanes_per_wave <= 0 ? (n_episodes + 255) / 256 : lanes_per_wave;
   if (lanes > 64) lanes = 64;
   a.lanes = lanes;
@@ -182,7 +222,6 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
   const int wpb = serl_waves_per_block(nwaves);
   a.block = 64 * wpb;
   const int grid = (nwaves + wpb - 1) / wpb;
-  hipStream_t stream = (hipStream_t)stream_;
   HIP_TRY(hipEventRecord(c->ev0, stream));
   if (s.code == SERL_DYN_NOMINAL) serl_launch_dyn_nominal(a, cmds, states, T, grid, stream);
   else serl_launch_dyn_ice(a, cmds, states, T, grid, stream);

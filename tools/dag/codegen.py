@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""Generate the wave-cooperative model evaluation (serl_amd/csrc/gen/citation_<variant>_wave.inc) from the DAG.
+
+One model evaluation = ~1 500 scalar f64 operations of "glue" around ~80 table look-ups (symex.py).  On the GPU
+one wavefront owns one episode:
+
+  * the glue is emitted as plain SSA (`const double v123 = v77 * v100;`): every lane computes the same
+    values (wave-uniform), the compiler allocates registers and schedules; the operation order of the
+    reference binary is kept, nothing is re-associated;
+  * the look-ups are grouped into dependency ROUNDS (2 in the nominal model).  In each round the distinct
+    look-up inputs are put on a per-wave LDS blackboard, then
+        phase A: one lane per distinct (breakpoint vector, input) pair finds the interval index,
+        phase B: one lane per look-up interpolates (pass 0: all 2-D tables, pass 1: all 1-D tables),
+    and the glue reads the results back as wave-uniform LDS loads.
+
+Usage: python tools/dag/codegen.py [variant ...]      (products are committed)
+"""
+import os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import build_dag, symex, interp
+
+LOOKUPS = ('l2d', 'l1d')
+
+
+def hexf(bits):
+    x = symex.b2f(bits)
+    if x != x:
+        return '__longlong_as_double(0x%016xLL)' % bits
+    if x in (float('inf'), float('-inf')):
+        return '(%s__builtin_inf())' % ('-' if x < 0 else '')
+    s = x.hex()
+    if s.startswith('-'):
+        return '(%s)' % s
+    return s
+
+
+class Gen:
+    def __init__(self, variant, fast_zero=False):
+        self.variant = variant
+        self.g, self.res, self.datas = build_dag.build(variant, fast_zero=fast_zero)
+        inc = open(os.path.join(build_dag.ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s.inc' % variant)).read()
+        import re
+        self.ro_base = int(re.search(r'#define RO_BASE (0x[0-9a-f]+)', inc).group(1), 16)
+        self.ro_lo = int(re.search(r'#define RO_USED_LO (0x[0-9a-f]+)', inc).group(1), 16)
+        self.ro_hi = int(re.search(r'#define RO_USED_HI (0x[0-9a-f]+)', inc).group(1), 16)
+        self.low = self.ro_lo >> 3
+        g = self.g
+        mj, mn = self.res[1]['outs'], self.res[0]['outs']
+        self.xdot = [mj['XDOT%d' % i] for i in range(19)]
+        self.single = self.xdot == [mn['XDOT%d' % i] for i in range(19)]
+        if not self.single:
+            raise NotImplementedError('major / minor derivative DAGs differ for %s' % variant)
+        self.dw_out = {int(k[2:]): v for k, v in mj.items() if k.startswith('DW')}
+        self.stop = mj['STOP0']
+        for i in range(12):
+            assert g.nodes[mj['Y%d' % i]] == ('in', 'X', i), 'rtY latch is not a copy of X'
+        self.roots = self.xdot + list(self.dw_out.values()) + [self.stop]
+        self.order = interp.topo(g, self.roots)
+        # ---- look-up rounds
+        self.rnd = {}
+        for n in self.order:
+            r = max([self.rnd[c] for c in build_dag.children(g, n)], default=0)
+            if g.nodes[n][0] in LOOKUPS:
+                r += 1
+            self.rnd[n] = r
+        self.nrounds = max(self.rnd.values())
+        self.rounds = []
+        for r in range(1, self.nrounds + 1):
+            l2 = [n for n in self.order if g.nodes[n][0] == 'l2d' and self.rnd[n] == r]
+            l1 = [n for n in self.order if g.nodes[n][0] == 'l1d' and self.rnd[n] == r]
+            ins, searches = [], []
+            def slot(lst, key):
+                if key not in lst:
+                    lst.append(key)
+                return lst.index(key)
+            L2, L1 = [], []
+            for n in l2:
+                t = g.nodes[n]
+                i0, i1 = slot(ins, t[6]), slot(ins, t[7])
+                sx, sy = slot(searches, (t[1], t[2], i0)), slot(searches, (t[3], t[4], i1))
+                L2.append(dict(node=n, xr=t[1], nr=t[2], xc=t[3], nc=t[4], z=t[5], sx=sx, sy=sy, in0=i0, in1=i1))
+            for n in l1:
+                t = g.nodes[n]
+                i0 = slot(ins, t[4])
+                sx = slot(searches, (t[1], t[2], i0))
+                L1.append(dict(node=n, x=t[1], n=t[2], y=t[3], sx=sx, in0=i0))
+            assert len(ins) <= 32 and len(searches) <= 64, (len(ins), len(searches))
+            assert len(L2) <= 64 and len(L1) <= 64, (len(L2), len(L1))
+            self.rounds.append(dict(ins=ins, searches=searches, L2=L2, L1=L1,
+                                    maxn=max(s[1] for s in searches)))
+        self.outslot = {}
+        for r, R in enumerate(self.rounds):
+            for k, e in enumerate(R['L2']):
+                self.outslot[e['node']] = (r, k)
+            for k, e in enumerate(R['L1']):
+                self.outslot[e['node']] = (r, 64 + k)
+
+    # ---- expression of a node -----------------------------------------------------------------------
+    def ref(self, n):
+        g = self.g
+        t = g.nodes[n]
+        op = t[0]
+        if op == 'cf':
+            return hexf(t[1])
+        if op == 'ci':
+            return '%dLL' % t[1]
+        if op == 'true':
+            return 'true'
+        if op == 'false':
+            return 'false'
+        if op == 'in':
+            if t[1] == 'RO':
+                return 'g_ro[%d]' % ((t[2] >> 3) - self.low)
+            if t[1] == 'T':
+                return 'T'
+            if t[1] == 'DW':
+                return 'w.DW[%d]' % t[2]
+            return '%s[%d]' % (t[1], t[2])
+        if op == 'in_i':
+            return '(long long)TICK'
+        return {'f': 'v%d', 'b': 'b%d', 'i': 'i%d'}[g.ty[n]] % n
+
+    BIN = dict(add='+', sub='-', mul='*', div='/', gt='>', ge='>=', lt='<', le='<=', eq='==', ne='!=')
+    FN1 = dict(sqrt='sqrt', exp='exp', log10='log10', log='log', sin='sin', cos='cos', tan='tan', atan='atan', asin='asin',
+               acos='acos', floor='floor', fabs='fabs')
+
+    def stmt(self, n):
+        g = self.g
+        t = g.nodes[n]
+        op = t[0]
+        R = self.ref
+        if op in ('cf', 'ci', 'true', 'false', 'in', 'in_i'):
+            return None
+        ty = {'f': 'const double', 'b': 'const bool', 'i': 'const long long'}[g.ty[n]]
+        name = R(n)
+        if op in self.BIN:
+            e = '%s %s %s' % (R(t[1]), self.BIN[op], R(t[2]))
+        elif op == 'neg':
+            e = '-%s' % R(t[1])
+        elif op in self.FN1:
+            e = '%s(%s)' % (self.FN1[op], R(t[1]))
+        elif op in ('pow', 'atan2'):
+            e = '%s(%s, %s)' % (op, R(t[1]), R(t[2]))
+        elif op == 'powsnf':
+            e = 'citw_powd_snf(%s, %s)' % (R(t[1]), R(t[2]))
+        elif op == 'sel':
+            e = '%s ? %s : %s' % (R(t[1]), R(t[2]), R(t[3]))
+        elif op == 'bnot':
+            e = '!%s' % R(t[1])
+        elif op == 'band':
+            e = '%s && %s' % (R(t[1]), R(t[2]))
+        elif op == 'bor':
+            e = '%s || %s' % (R(t[1]), R(t[2]))
+        elif op == 'unord':
+            e = '(%s != %s) || (%s != %s)' % (R(t[1]), R(t[1]), R(t[2]), R(t[2]))
+        elif op in LOOKUPS:
+            r, k = self.outslot[n]
+            e = 'w.out[%d][%d]' % (r, k)
+        elif op == 'table3':
+            e = 'citw_table3(g_t3, %s, %s, %s)' % (R(t[1]), R(t[2]), R(t[3]))
+        elif op == 'iadd':
+            e = '%s + %s' % (R(t[1]), R(t[2]))
+        elif op == 'i2d':
+            e = '(double)(%s)' % R(t[1])
+        elif op in ('fxor', 'fand', 'for'):
+            e = 'citw_u2d(citw_d2u(%s) %s citw_d2u(%s))' % (R(t[1]), {'fxor': '^', 'fand': '&', 'for': '|'}[op], R(t[2]))
+        elif op == 'fandn':
+            e = 'citw_u2d(~citw_d2u(%s) & citw_d2u(%s))' % (R(t[1]), R(t[2]))
+        elif op == 'fmask':
+            e = 'citw_u2d(%s ? ~0ULL : 0ULL)' % R(t[1])
+        elif op == 'bits':
+            e = '(long long)citw_d2u(%s)' % R(t[1])
+        elif op in ('sc_sin', 'sc_cos'):
+            return None       # emitted as a pair by emit()
+        else:
+            raise NotImplementedError(op)
+        return '  %s %s = %s;' % (ty, name, e)
+
+    def emit(self):
+        g = self.g
+        V = self.variant
+        out = []
+        P = out.append
+        P('/* GENERATED by tools/dag/codegen.py from gen/citation_%s.inc -- do not edit.' % V)
+        P(' * Wave-cooperative evaluation of the %s model: %d live nodes, %d look-up round(s).' % (V, len(self.order), self.nrounds))
+        P(' * Operation order of every f64 expression is that of the reference binary (tools/dag/symex.py). */')
+        cnt = collections.Counter(g.nodes[n][0] for n in self.order)
+        P('/* node census: %s */' % ', '.join('%s %d' % kv for kv in cnt.most_common()))
+        P('#define CITW_%s_ROUNDS %d' % (V.upper(), self.nrounds))
+        P('enum { citw_%s_ROUNDS = %d, citw_%s_RO_BASE_W = %d, citw_%s_RO_LO_W = %d, citw_%s_RO_HI_W = %d };  /* f64 word range of .rodata the model reads */'
+          % (V, self.nrounds, V, self.ro_base >> 3, V, self.ro_lo >> 3, V, self.ro_hi >> 3))
+        lw = self.low
+        # ---- descriptor tables
+        P('static __device__ const CitwSearch citw_%s_search[%d][64] = {' % (V, self.nrounds))
+        for R in self.rounds:
+            rows = ['{%d, %d, %d, 0}' % ((s[0] >> 3) - lw, s[1], s[2]) for s in R['searches']]
+            rows += ['{0, 2, 0, 0}'] * (64 - len(rows))
+            P('  {' + ', '.join(rows) + '},')
+        P('};')
+        P('static __device__ const CitwLookup citw_%s_lookup[%d][2][64] = {' % (V, self.nrounds))
+        for R in self.rounds:
+            rows2 = ['{%d, %d, %d, %d, %d, %d, %d, %d, %d}' % ((e['xr'] >> 3) - lw, e['nr'], (e['xc'] >> 3) - lw, (e['z'] >> 3) - lw, e['sx'], e['sy'],
+                                                               e['in0'], e['in1'], k) for k, e in enumerate(R['L2'])]
+            rows2 += ['{0, 2, 0, 0, 63, 63, 0, 0, 127}'] * (64 - len(rows2))
+            rows1 = ['{%d, %d, 0, %d, %d, 0, %d, 0, %d}' % ((e['x'] >> 3) - lw, e['n'], (e['y'] >> 3) - lw, e['sx'], e['in0'], 64 + k)
+                     for k, e in enumerate(R['L1'])]
+            rows1 += ['{0, 2, 0, 0, 63, 0, 0, 0, 127}'] * (64 - len(rows1))
+            P('  {{' + ', '.join(rows2) + '},')
+            P('   {' + ', '.join(rows1) + '}},')
+        P('};')
+        # ---- the evaluation function
+        P('static __device__ __forceinline__ void citw_%s_eval(CitwWave &w, const CitwSearch (*S)[64], const CitwLookup (*L)[2][64],' % V)
+        P('    const double (&X)[19], const double (&CMD)[10], const double T, const unsigned TICK, const bool major,')
+        P('    double (&XDOT)[19], double &STOP)')
+        P('{')
+        P('  const int lane = threadIdx.x & 63;')
+        emitted = set()
+
+        def emit_node(n):
+            # iterative post-order over un-emitted children
+            stack = [(n, False)]
+            while stack:
+                m, done = stack.pop()
+                if m in emitted:
+                    continue
+                if done:
+                    emitted.add(m)
+                    t = g.nodes[m]
+                    if t[0] in ('sc_sin', 'sc_cos'):
+                        s_, c_ = g.memo.get(('sc_sin', t[1])), g.memo.get(('sc_cos', t[1]))
+                        P('  double v%d, v%d; sincos(%s, &v%d, &v%d);' % (s_, c_, self.ref(t[1]), s_, c_))
+                        emitted.add(s_); emitted.add(c_)
+                        continue
+                    s = self.stmt(m)
+                    if s:
+                        P(s)
+                    continue
+                stack.append((m, True))
+                for c in build_dag.children(g, m):
+                    if c not in emitted:
+                        stack.append((c, False))
+
+        for r, R in enumerate(self.rounds):
+            P('  /* ---- look-up round %d: %d inputs, %d index searches, %d 2-D + %d 1-D tables */' %
+              (r + 1, len(R['ins']), len(R['searches']), len(R['L2']), len(R['L1'])))
+            for n in R['ins']:
+                emit_node(n)
+            P('  if (lane == 0) {')
+            for k, n in enumerate(R['ins']):
+                P('    w.in[%d] = %s;' % (k, self.ref(n)))
+            P('  }')
+            P('  citw_search<%d>(w, S[%d], lane);' % (R['maxn'], r))
+            if R['L2']:
+                P('  citw_lookup2d(w, L[%d][0], w.out[%d], lane);' % (r, r))
+            if R['L1']:
+                P('  citw_lookup1d(w, L[%d][1], w.out[%d], lane);' % (r, r))
+            for e in R['L2'] + R['L1']:
+                emitted.add(e['node'])
+                P(self.stmt(e['node']))
+        P('  /* ---- derivatives */')
+        for i, n in enumerate(self.xdot):
+            emit_node(n)
+            P('  XDOT[%d] = %s;' % (i, self.ref(n)))
+        P('  if (major) {   /* major step only: solver stop time, Derivative-block banks */')
+        emit_node(self.stop)
+        P('    STOP = %s;' % self.ref(self.stop))
+        for k, n in sorted(self.dw_out.items()):
+            emit_node(n)
+        P('    if (lane == 0) {')
+        for k, n in sorted(self.dw_out.items()):
+            if g.nodes[n] != ('in', 'DW', k):
+                P('      w.DW[%d] = %s;' % (k, self.ref(n)))
+        P('    }')
+        P('  }')
+        P('}')
+        return '\n'.join(out) + '\n'
+
+
+def main():
+    variants = [a for a in sys.argv[1:] if not a.startswith('--')] or ['nominal']
+    for v in variants:
+        gen = Gen(v, fast_zero='--fast-zero' in sys.argv)
+        text = gen.emit()
+        path = os.path.join(build_dag.ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_wave.inc' % v)
+        open(path, 'w').write(text)
+        print('%s: %d lines, rounds %s' % (path, text.count('\n'),
+                                            [(len(R['ins']), len(R['searches']), len(R['L2']), len(R['L1'])) for R in gen.rounds]))
+
+
+if __name__ == '__main__':
+    main()

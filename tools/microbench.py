@@ -9,7 +9,7 @@ from serl_amd import refsignals
 eng = serl_amd.RolloutEngine(0)
 res = {}
 T = 400
-for E, lanes in [(1, 1), (150, 1), (150, 64), (1024, 1), (4096, 4), (4096, 64)]:
+for E, lanes in [(1, 0), (150, 0), (192, 0), (768, 0), (1024, 0), (2048, 0), (150, 1), (4096, 64)]:
     cmds = np.zeros((E, T, 10)); cmds[:, :, 0] = 0.01 * np.sin(np.arange(T) * 0.01)[None]
     eng.dynamics_open_loop(cmds, lanes_per_wave=lanes)
     eng.dynamics_open_loop(cmds, lanes_per_wave=lanes)
@@ -19,7 +19,7 @@ w = torch.from_numpy(np.load('tests/golden/actors.npz')['serl50'])
 spec = serl_amd.NetSpec(7, 3, 32, 3, 'tanh')
 ref = refsignals.tabulate(*refsignals.base_reference(4), 4)
 n = ref.shape[0]
-for E, lanes in [(1, 1), (150, 1), (150, 64), (4096, 64)]:
+for E, lanes in [(1, 0), (150, 0), (192, 0), (768, 0), (1024, 0), (2048, 0), (4096, 0), (150, 1), (4096, 64)]:
     moe = np.arange(E) % 50
     eng.rollout(w, spec, moe, ref, t_max=4, lanes_per_wave=lanes)
     out = eng.rollout(w, spec, moe, ref, t_max=4, lanes_per_wave=lanes)
