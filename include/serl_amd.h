@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SERL_ABI_VERSION 1
+#define SERL_ABI_VERSION 2
 
 enum serl_error {
   SERL_OK = 0,
@@ -86,6 +86,12 @@ typedef struct serl_rollout_desc {
                                        (envs/phlabenv.py:401-428 never clears self.error) or NULL=0 */
   const double *action_noise;       /* [n_episodes][max_steps][3] pre-drawn clipped Gaussian noise
                                        (base/core/agent.py:90-93) or NULL */
+  const int32_t *tick0;             /* [n_episodes] model clock (clockTick0) the episode starts with, or NULL = 0.
+                                       The reference's initialize() @0xb4e0 resets the states but NOT the model
+                                       clock (rtM clockTick0/1 and t keep counting across episodes of one process;
+                                       probed on the live library), which only matters to the time-switched builds
+                                       cg_timed ("CG aft after 20 s") and gust: there every episode after the first
+                                       of a process starts at tick0 = steps simulated so far (incl. one per reset) */
   double t_max;                     /* 80 (eval) / 20 (train) seconds */
   int32_t max_steps;                /* rows in ref / trace buffers; 8001 for t_max = 80 */
   int32_t lanes_per_wave;           /* 0 = auto; episodes packed per 64-lane wavefront (1..64) */
@@ -120,8 +126,9 @@ int serl_dyn_open_loop(serl_ctx *ctx, int slot, int32_t n_episodes, int32_t T, c
                        double *states, int32_t lanes_per_wave, void *stream);
 
 /* Development aid: with SERL_PROFILE=1 in the environment serl_rollout records shader-clock cycles of wave 0 of
- * workgroup 0: out = {actor forward, dynamics step, env bookkeeping, env steps}. */
-int serl_debug_profile(serl_ctx *ctx, unsigned long long out[4]);
+ * workgroup 0: out[0..3] = {actor forward, dynamics step, env bookkeeping, env steps}; out[4..31] = phase
+ * counters of the model evaluation (non-zero only in builds compiled with -DCITW_PROFILE). */
+int serl_debug_profile(serl_ctx *ctx, unsigned long long out[32]);
 
 /* Duration (ms) of the most recent serl_rollout kernel on its stream, measured with HIP events
  * recorded around the launch; blocks until that kernel has finished. */

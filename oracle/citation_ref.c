@@ -67,6 +67,14 @@ void cit_reset(CitInstance *I, int code, const double *ro, const double *t3, con
   c->ro = ro; c->t3 = t3; c->dt = dt; c->major = 1; c->tick = 0; c->t = 0.0;
 }
 
+/* The reference's initialize() does not reset the model clock (clockTick0 @rtM+0xba18, t @+0xbac0 keep their
+ * values; probed on the live cg_timed library): an episode that is not the first of its process starts here. */
+void cit_set_clock(CitInstance *I, unsigned tick)
+{
+  I->c.tick = tick;
+  I->c.t = (double)tick * I->c.dt;
+}
+
 int cit_step(CitInstance *I, const double *cmd, double *out)
 {
   switch (I->code) {

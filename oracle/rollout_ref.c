@@ -27,12 +27,72 @@ int cit_instance_size(void);
 void cit_reset(CitInstance *I, int code, const double *ro, const double *t3, const double *x0,
                const double *dw0, double dt);
 int cit_step(CitInstance *I, const double *cmd, double *out);
+void cit_set_clock(CitInstance *I, unsigned tick);
+
+#define DET_FN inline
+static inline double det_pow2(long long k) { union { unsigned long long u; double d; } c; c.u = (unsigned long long)(k + 1023) << 52; return c.d; }
+#define DET_POW2(k) det_pow2(k)
+
+/* tanh / expm1 of the f32 actor, evaluated in f64 with + - * / only (no libm, no FMA contraction), so that the
+ * CPU oracle and the HIP kernel return bit-identical f32 activations (specified in include/serl_amd.h):
+ *   z = 2|x| (tanh) or x (expm1, x <= 0);  k = round(z / ln2);  r = (z - k*LN2_HI) - k*LN2_LO;
+ *   q = expm1(r) by the Taylor polynomial through r^13/13! in Horner form;
+ *   tanh = q/(q+2) if k == 0 else 1 - 2/(2^k (q+1) + 1);   expm1 = q if k == 0 else 2^k (q+1) - 1;
+ * the f64 result (error ~1e-16) is rounded to f32 once. */
+static DET_FN double det_expm1_reduced(double z, long long *kout)
+{
+  const double INVLN2 = 1.4426950408889634, LN2_HI = 0.6931471803691238, LN2_LO = 1.9082149292705877e-10;
+  const double v = z * INVLN2;
+  const long long k = v < 0.0 ? -(long long)(0.5 - v) : (long long)(v + 0.5);
+  const double kd = (double)k;
+  const double r = (z - kd * LN2_HI) - kd * LN2_LO;
+  double p = 1.6059043836821613e-10;            /* 1/13! */
+  p = p * r + 2.08767569878681e-09;             /* 1/12! */
+  p = p * r + 2.505210838544172e-08;            /* 1/11! */
+  p = p * r + 2.755731922398589e-07;            /* 1/10! */
+  p = p * r + 2.7557319223985893e-06;           /* 1/9! */
+  p = p * r + 2.48015873015873e-05;             /* 1/8! */
+  p = p * r + 0.0001984126984126984;            /* 1/7! */
+  p = p * r + 0.001388888888888889;             /* 1/6! */
+  p = p * r + 0.008333333333333333;             /* 1/5! */
+  p = p * r + 0.041666666666666664;             /* 1/4! */
+  p = p * r + 0.16666666666666666;              /* 1/3! */
+  p = p * r + 0.5;                              /* 1/2! */
+  *kout = k;
+  return r + (r * r) * p;
+}
+
+static DET_FN float det_tanhf(float xf)
+{
+  if (xf != xf) return xf;
+  const double x = (double)xf;
+  const double ax = x < 0.0 ? -x : x;
+  double t;
+  if (ax > 20.0) t = 1.0;
+  else {
+    long long k;
+    const double q = det_expm1_reduced(ax + ax, &k);
+    if (k == 0) t = q / (q + 2.0);
+    else t = 1.0 - 2.0 / (DET_POW2(k) * (q + 1.0) + 1.0);
+  }
+  return (float)(x < 0.0 ? -t : t);
+}
+
+static DET_FN float det_expm1f_neg(float xf)     /* x <= 0 (the ELU branch) */
+{
+  if (xf != xf) return xf;
+  const double x = (double)xf;
+  if (x < -104.0) return -1.0f;
+  long long k;
+  const double q = det_expm1_reduced(x, &k);
+  return (float)(k == 0 ? q : DET_POW2(k) * (q + 1.0) - 1.0);
+}
 
 static float act_f(float v, int act)
 {
   switch (act) {
-    case SERL_ACT_TANH: return tanhf(v);
-    case SERL_ACT_ELU: return v > 0.0f ? v : expm1f(v);
+    case SERL_ACT_TANH: return det_tanhf(v);
+    case SERL_ACT_ELU: return v > 0.0f ? v : det_expm1f_neg(v);
     default: return v > 0.0f ? v : 0.01f * v;
   }
 }
@@ -71,7 +131,7 @@ static void actor_forward(const serl_rollout_desc *d, const float *w, const floa
   for (int i = 0; i < A; ++i) {
     float acc = bo[i];
     for (int j = 0; j < H; ++j) acc = acc + Wo[i * H + j] * h0[j];
-    act_out[i] = tanhf(acc);
+    act_out[i] = det_tanhf(acc);
   }
 }
 
@@ -97,6 +157,7 @@ static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, in
 
   /* reset (phlabenv.py:401-428) */
   cit_reset(I, bd->code, bd->ro, bd->t3, bd->x0, bd->dw0, bd->dt);
+  if (d->tick0) cit_set_clock(I, (unsigned)d->tick0[e]);   /* initialize() leaves the model clock running */
   memset(cmd, 0, sizeof(cmd));
   cmd[0] = clipd(cmd[0] * f->elev_gain, -f->elev_clip, f->elev_clip);
   cmd[1] = clipd(cmd[1], -f->ail_clip, f->ail_clip);

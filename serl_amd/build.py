@@ -11,7 +11,11 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libserl_amd.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 UNITS = ['serl_capi.hip', 'rollout_nominal.hip', 'rollout_ice.hip', 'rollout_wave_nominal.hip']
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-Wno-unused-value']
+# -ffp-contract=off: the IEEE-754 operation order of the reference binary is part of the contract (no FMA fusion).
+# -disable-machine-licm: the model evaluation is inlined into the ODE5 stage loop; hoisting its ~110 f64 literals
+# out of the loop (2 SGPRs each) makes them spill -- rematerialising them at use is cheaper.
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-Wno-unused-value',
+         '-DCITW_EVAL_INLINE=__forceinline__', '-mllvm', '-disable-machine-licm']
 
 
 def _deps():
@@ -24,15 +28,18 @@ def _deps():
     return out
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=(), lib=None, tag=''):
+    """extra_flags / lib / tag build a variant next to the product library (e.g. the phase-profiling build:
+    extra_flags=['-DCITW_PROFILE'], lib='libserl_amd_prof.so', tag='_prof')."""
+    LIB = os.path.join(CSRC, lib) if lib else globals()['LIB']
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in _deps()):
         return LIB
     objdir = os.path.join(CSRC, 'build')
     os.makedirs(objdir, exist_ok=True)
 
     def cc(unit):
-        obj = os.path.join(objdir, unit.replace('.hip', '.o'))
-        cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, unit), '-o', obj]
+        obj = os.path.join(objdir, unit.replace('.hip', tag + '.o'))
+        cmd = [HIPCC] + FLAGS + list(extra_flags) + ['-c', os.path.join(CSRC, unit), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (unit, r.stderr[-4000:]))

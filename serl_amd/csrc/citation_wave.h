@@ -12,7 +12,7 @@
 //   citw_lookup1d   one lane per 1-D table: rt_Lookup @0xf530   (y1-y0)/(x1-x0)*(u-x0)+y0
 //   citw_table3     the `table3` S-function (mdlOutputs @0x10da0, Table2 @0x10a30), wave-uniform
 //
-// Inputs and results travel over a per-wave LDS blackboard (CitwWave); the model tables sit in LDS once per
+// Inputs and results travel over per-wave LDS blackboards (g_in / g_sidx / g_out*); the model tables sit in LDS once per
 // workgroup (g_ro, 94 KiB).  Within a wavefront LDS operations complete in order, so no barrier is needed
 // between the phases.
 #pragma once
@@ -25,19 +25,36 @@
 struct CitwSearch { uint16_t xw, n, in, pad; };                                 // 8 B
 struct CitwLookup { uint16_t xrw, nr, xcw, zw, sx, sy, in0, in1, out, p0, p1, p2; };   // 24 B; 1-D: x = xrw, y = zw
 
-struct CitwWave {                     // per-wavefront LDS scratch
-  double in[32];                      // look-up inputs of the current round
-  double out[CITW_MAX_ROUNDS][128];   // look-up results: [round][0..63] 2-D pass, [64..127] 1-D pass
-  int sidx[64];                       // interval indices of the current round
-  double DW[32];                      // Derivative-block banks (rtDW): TimeStampA, LastUAtTimeA[12], TimeStampB, LastUAtTimeB[12]
-  double f[6][20];                    // ODE5 stage derivatives
-  double xs[20];                      // stage state exchange (lane i <-> wave-uniform)
-};
+// Per-wavefront LDS scratch, one row per wavefront of the workgroup.  Separate objects (not one struct) so that the
+// compiler can tell the blackboards apart: results of look-up round 1 stay loadable across the stores of round 2.
+#define CITW_MAX_WAVES 4
+__shared__ double g_in[CITW_MAX_WAVES][32];       // look-up inputs of the current round
+__shared__ int g_sidx[CITW_MAX_WAVES][64];        // interval indices of the current round
+__shared__ double g_out0[CITW_MAX_WAVES][128];    // look-up results of round 1: [0..63] 2-D pass, [64..127] 1-D pass
+__shared__ double g_out1[CITW_MAX_WAVES][128];    // ... round 2
+__shared__ double g_out2[CITW_MAX_WAVES][128];    // ... round 3
+__shared__ double g_dw[CITW_MAX_WAVES][32];       // Derivative-block banks (rtDW): TimeStampA, LastUAtTimeA[12], TimeStampB, LastUAtTimeB[12]
+__shared__ double g_f[CITW_MAX_WAVES][6][20];     // ODE5 stage derivatives
+__shared__ double g_xs[CITW_MAX_WAVES][20];       // continuous states X[19] of the current stage (lane i writes state i)
+__shared__ double g_cmd[CITW_MAX_WAVES][12];      // command vector of the current env step
 
 __shared__ double g_ro[CITW_RO_LDS_WORDS];
 __shared__ double g_t3[48];
 __shared__ CitwSearch g_S[CITW_MAX_ROUNDS][64];
 __shared__ CitwLookup g_L[CITW_MAX_ROUNDS][2][64];
+
+// Phase profile of the model evaluation (profiling builds only, -DCITW_PROFILE): shader-clock cycles of wave 0 of
+// workgroup 0 between the CITW_T marks of the generated code, accumulated in LDS and copied out by the kernel.
+#ifdef CITW_PROFILE
+__shared__ unsigned long long g_prof[32];
+__shared__ unsigned long long g_tlast;
+#define CITW_T0() do { if (blockIdx.x == 0 && threadIdx.x == 0) g_tlast = __builtin_readcyclecounter(); } while (0)
+#define CITW_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+                         g_prof[(k)] += t_ - g_tlast; g_tlast = t_; } } while (0)
+#else
+#define CITW_T0() ((void)0)
+#define CITW_T(k) ((void)0)
+#endif
 
 static __device__ __forceinline__ unsigned long long citw_d2u(double d) { return (unsigned long long)__double_as_longlong(d); }
 static __device__ __forceinline__ double citw_u2d(unsigned long long u) { return __longlong_as_double((long long)u); }
@@ -45,10 +62,10 @@ static __device__ __forceinline__ double citw_u2d(unsigned long long u) { return
 // interval index (rt_GetLookupIndex semantics):
 //   u <= x[0] -> 0 ; u >= x[n-1] -> n-2 ; u < 0: x[i] <= u < x[i+1] ; u >= 0: x[i] < u <= x[i+1]
 template <int MAXN>
-static __device__ __forceinline__ void citw_search(CitwWave &w, const CitwSearch *S, int lane)
+static __device__ __forceinline__ void citw_search(const int wv, const CitwSearch *S, int lane)
 {
   const CitwSearch d = S[lane];
-  const double u = w.in[d.in];
+  const double u = g_in[wv][d.in];
   const double *x = g_ro + d.xw;
   const int n = d.n;
   int lt = 0, le = 0;
@@ -62,14 +79,15 @@ static __device__ __forceinline__ void citw_search(CitwWave &w, const CitwSearch
   int idx = ((u < 0.0) ? le : lt) - 1;
   idx = idx < 0 ? 0 : idx;
   idx = idx > n - 2 ? n - 2 : idx;
-  w.sidx[lane] = idx;
+  g_sidx[wv][lane] = idx;
 }
 
-static __device__ __forceinline__ void citw_lookup2d(CitwWave &w, const CitwLookup *L, double *out, int lane)
+template <typename OUT>
+static __device__ __forceinline__ void citw_lookup2d(const int wv, const CitwLookup *L, OUT &out, int lane)
 {
   const CitwLookup d = L[lane];
-  const int ix = w.sidx[d.sx], iy = w.sidx[d.sy];
-  const double u0 = w.in[d.in0], u1 = w.in[d.in1];
+  const int ix = g_sidx[wv][d.sx], iy = g_sidx[wv][d.sy];
+  const double u0 = g_in[wv][d.in0], u1 = g_in[wv][d.in1];
   const double *xr = g_ro + d.xrw, *xc = g_ro + d.xcw, *z = g_ro + d.zw;
   const int nr = d.nr;
   const double x0 = xr[ix], x1 = xr[ix + 1];
@@ -81,20 +99,21 @@ static __device__ __forceinline__ void citw_lookup2d(CitwWave &w, const CitwLook
   const double y0 = xc[iy];
   const double dy = xc[iy + 1] - y0;
   double r = b - a; r = r / dy; r = r * (u1 - y0);
-  out[d.out] = r + a;
+  out[wv][d.out] = r + a;
 }
 
-static __device__ __forceinline__ void citw_lookup1d(CitwWave &w, const CitwLookup *L, double *out, int lane)
+template <typename OUT>
+static __device__ __forceinline__ void citw_lookup1d(const int wv, const CitwLookup *L, OUT &out, int lane)
 {
   const CitwLookup d = L[lane];
-  const int i = w.sidx[d.sx];
-  const double u = w.in[d.in0];
+  const int i = g_sidx[wv][d.sx];
+  const double u = g_in[wv][d.in0];
   const double *x = g_ro + d.xrw, *y = g_ro + d.zw;
   const double x0 = x[i], x1 = x[i + 1], y0 = y[i], y1 = y[i + 1];
   double r = y1 - y0;
   r = r / (x1 - x0);
   r = r * (u - x0);
-  out[d.out] = r + y0;
+  out[wv][d.out] = r + y0;
 }
 
 // ---- table3 S-function: 3-D table, linear interpolation.  The reference walks linearly from an interval cached in
@@ -152,11 +171,10 @@ __device__ static const double citw_ode5_B[6][6] = {
   {0.09114583333333333, 0.0, 0.44923629829290207, 0.6510416666666666, -0.322376179245283, 0.13095238095238096},
 };
 
-// Per-episode dynamics state of the wave kernel: the 19 continuous states are wave-uniform (every lane holds the
-// same value); lane i < 19 additionally keeps state i privately for the lane-parallel ODE5 combination.
+// Per-episode dynamics state of the wave kernel: lane i < 19 keeps continuous state i (ODE5 combination per lane);
+// the model evaluation reads all 19 as wave-uniform LDS loads from g_xs.
 struct CitwState {
-  double X[19];
-  double xi;          // this lane's own state component (lane < 19)
+  double xi;          // this lane's own state component (lane < 19); the wave-uniform copy lives in g_xs
   double t;           // model time
   unsigned tick;      // clockTick0
 };

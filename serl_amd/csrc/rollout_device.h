@@ -21,10 +21,68 @@ struct RolloutArgs {
   unsigned long long *prof;           // optional [4] cycle counters of wave 0 / block 0: actor, dynamics, env, steps
 };
 
+#define DET_FN __device__ __forceinline__
+#define DET_POW2(k) __longlong_as_double((long long)((k) + 1023) << 52)
+
+/* tanh / expm1 of the f32 actor (product code; the oracle restates the same arithmetic), evaluated in f64 with + - * / only (no libm, no FMA contraction), so that the
+ * CPU oracle and the HIP kernel return bit-identical f32 activations (specified in include/serl_amd.h):
+ *   z = 2|x| (tanh) or x (expm1, x <= 0);  k = round(z / ln2);  r = (z - k*LN2_HI) - k*LN2_LO;
+ *   q = expm1(r) by the Taylor polynomial through r^13/13! in Horner form;
+ *   tanh = q/(q+2) if k == 0 else 1 - 2/(2^k (q+1) + 1);   expm1 = q if k == 0 else 2^k (q+1) - 1;
+ * the f64 result (error ~1e-16) is rounded to f32 once. */
+static DET_FN double det_expm1_reduced(double z, long long *kout)
+{
+  const double INVLN2 = 1.4426950408889634, LN2_HI = 0.6931471803691238, LN2_LO = 1.9082149292705877e-10;
+  const double v = z * INVLN2;
+  const long long k = v < 0.0 ? -(long long)(0.5 - v) : (long long)(v + 0.5);
+  const double kd = (double)k;
+  const double r = (z - kd * LN2_HI) - kd * LN2_LO;
+  double p = 1.6059043836821613e-10;            /* 1/13! */
+  p = p * r + 2.08767569878681e-09;             /* 1/12! */
+  p = p * r + 2.505210838544172e-08;            /* 1/11! */
+  p = p * r + 2.755731922398589e-07;            /* 1/10! */
+  p = p * r + 2.7557319223985893e-06;           /* 1/9! */
+  p = p * r + 2.48015873015873e-05;             /* 1/8! */
+  p = p * r + 0.0001984126984126984;            /* 1/7! */
+  p = p * r + 0.001388888888888889;             /* 1/6! */
+  p = p * r + 0.008333333333333333;             /* 1/5! */
+  p = p * r + 0.041666666666666664;             /* 1/4! */
+  p = p * r + 0.16666666666666666;              /* 1/3! */
+  p = p * r + 0.5;                              /* 1/2! */
+  *kout = k;
+  return r + (r * r) * p;
+}
+
+static DET_FN float det_tanhf(float xf)
+{
+  if (xf != xf) return xf;
+  const double x = (double)xf;
+  const double ax = x < 0.0 ? -x : x;
+  double t;
+  if (ax > 20.0) t = 1.0;
+  else {
+    long long k;
+    const double q = det_expm1_reduced(ax + ax, &k);
+    if (k == 0) t = q / (q + 2.0);
+    else t = 1.0 - 2.0 / (DET_POW2(k) * (q + 1.0) + 1.0);
+  }
+  return (float)(x < 0.0 ? -t : t);
+}
+
+static DET_FN float det_expm1f_neg(float xf)     /* x <= 0 (the ELU branch) */
+{
+  if (xf != xf) return xf;
+  const double x = (double)xf;
+  if (x < -104.0) return -1.0f;
+  long long k;
+  const double q = det_expm1_reduced(x, &k);
+  return (float)(k == 0 ? q : DET_POW2(k) * (q + 1.0) - 1.0);
+}
+
 static __device__ __forceinline__ float serl_act(float v, int act)
 {
-  if (act == SERL_ACT_TANH) return tanhf(v);
-  if (act == SERL_ACT_ELU) return v > 0.0f ? v : expm1f(v);
+  if (act == SERL_ACT_TANH) return det_tanhf(v);
+  if (act == SERL_ACT_ELU) return v > 0.0f ? v : det_expm1f_neg(v);
   return v > 0.0f ? v : 0.01f * v;
 }
 
@@ -146,7 +204,7 @@ static __device__ void serl_actor_forward_wave(const serl_rollout_desc &dd, cons
       serl_load_chunk(wa, ro_, jc, H);
       acc = serl_mac_chunk(acc, wa, (jc < 64) ? h0a : h0b, jc & 63, jc, H);
     }
-    const float t = tanhf(acc);
+    const float t = det_tanhf(acc);
     for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, i);
   }
 }

@@ -151,8 +151,8 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   a.dyn_dt = s.dt;
   a.prof = nullptr;
   if (getenv("SERL_PROFILE")) {
-    if (!c->prof) HIP_TRY(hipMalloc((void **)&c->prof, 4 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(c->prof, 0, 4 * sizeof(unsigned long long), stream));
+    if (!c->prof) HIP_TRY(hipMalloc((void **)&c->prof, 32 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(c->prof, 0, 32 * sizeof(unsigned long long), stream));
     a.prof = c->prof;
   }
   int lanes = d->lanes_per_wave;
@@ -233,11 +233,11 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
 
 /* development aid (SERL_PROFILE=1): shader-clock cycles wave 0 of workgroup 0 spent in the actor forward, the
  * dynamics step and the env bookkeeping during the last serl_rollout, and its number of env steps */
-int serl_debug_profile(serl_ctx *c, unsigned long long out[4])
+int serl_debug_profile(serl_ctx *c, unsigned long long out[32])
 {
   if (!c || !out || !c->prof) return fail(SERL_E_INVALID, "serl_debug_profile: profiling not enabled (SERL_PROFILE=1)");
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, c->prof, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, c->prof, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return SERL_OK;
 }
 

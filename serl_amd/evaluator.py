@@ -81,7 +81,7 @@ class RolloutEngine:
 
     # ------------------------------------------------------------------------------------------
     def rollout(self, weights, spec: NetSpec, member_of_episode, ref, *, build='h2000_v90', faults=None,
-                err0=None, action_noise=None, t_max=80.0, traces=False, transitions=False,
+                err0=None, tick0=None, action_noise=None, t_max=80.0, traces=False, transitions=False,
                 lanes_per_wave=0, sync=True):
         """Low-level: run len(member_of_episode) episodes.  weights f32 [M, >=P] (device or host),
         ref f64 [E, T, 3] or [T, 3] radians.  Returns dict of device tensors."""
@@ -114,6 +114,9 @@ class RolloutEngine:
         if err0 is not None:
             e0 = torch.as_tensor(np.asarray(err0, dtype=np.float64).reshape(E, 3)).to(dev).contiguous()
             d.err0 = e0.data_ptr(); keep.append(e0)
+        if tick0 is not None:
+            tk = torch.as_tensor(np.asarray(tick0, dtype=np.int32).reshape(E)).to(dev).contiguous()
+            d.tick0 = tk.data_ptr(); keep.append(tk)
         if action_noise is not None:
             an = torch.as_tensor(action_noise, dtype=torch.float64).to(dev).contiguous()
             assert an.shape == (E, T, 3)

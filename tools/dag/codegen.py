@@ -35,8 +35,10 @@ def hexf(bits):
 
 
 class Gen:
-    def __init__(self, variant, fast_zero=False):
+    def __init__(self, variant, fast_zero=True, lds_consts=False):
         self.variant = variant
+        self.lds_consts = lds_consts
+        self.kslot = {}
         self.g, self.res, self.datas = build_dag.build(variant, fast_zero=fast_zero)
         inc = open(os.path.join(build_dag.ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s.inc' % variant)).read()
         import re
@@ -101,6 +103,10 @@ class Gen:
         t = g.nodes[n]
         op = t[0]
         if op == 'cf':
+            if self.lds_consts and t[1] not in (0,):
+                if t[1] not in self.kslot:
+                    self.kslot[t[1]] = len(self.kslot)
+                return 'g_k[%d]' % self.kslot[t[1]]
             return hexf(t[1])
         if op == 'ci':
             return '%dLL' % t[1]
@@ -114,8 +120,8 @@ class Gen:
             if t[1] == 'T':
                 return 'T'
             if t[1] == 'DW':
-                return 'w.DW[%d]' % t[2]
-            return '%s[%d]' % (t[1], t[2])
+                return 'g_dw[wv][%d]' % t[2]
+            return {'X': 'g_xs[wv][%d]', 'CMD': 'g_cmd[wv][%d]'}[t[1]] % t[2]
         if op == 'in_i':
             return '(long long)TICK'
         return {'f': 'v%d', 'b': 'b%d', 'i': 'i%d'}[g.ty[n]] % n
@@ -155,7 +161,7 @@ class Gen:
             e = '(%s != %s) || (%s != %s)' % (R(t[1]), R(t[1]), R(t[2]), R(t[2]))
         elif op in LOOKUPS:
             r, k = self.outslot[n]
-            e = 'w.out[%d][%d]' % (r, k)
+            e = 'g_out%d[wv][%d]' % (r, k)
         elif op == 'table3':
             e = 'citw_table3(g_t3, %s, %s, %s)' % (R(t[1]), R(t[2]), R(t[3]))
         elif op == 'iadd':
@@ -209,11 +215,15 @@ class Gen:
             P('   {' + ', '.join(rows1) + '}},')
         P('};')
         # ---- the evaluation function
-        P('static __device__ __forceinline__ void citw_%s_eval(CitwWave &w, const CitwSearch (*S)[64], const CitwLookup (*L)[2][64],' % V)
-        P('    const double (&X)[19], const double (&CMD)[10], const double T, const unsigned TICK, const bool major,')
-        P('    double (&XDOT)[19], double &STOP)')
+        P('/* state in g_xs[wv][19], command in g_cmd[wv][10] (wave-uniform LDS reads); derivatives -> g_f[wv][stage][19];')
+        P(' * major step: returns the solver stop time and updates the Derivative-block banks g_dw[wv] */')
+        P('static __device__ CITW_EVAL_INLINE double citw_%s_eval(const int wv, const int stage, const double T, const unsigned TICK)' % V)
         P('{')
+        P('  const CitwSearch (*S)[64] = g_S; const CitwLookup (*L)[2][64] = g_L;')
+        P('  const bool major = stage == 0;')
+        P('  double STOP = 0.0;')
         P('  const int lane = threadIdx.x & 63;')
+        P('  CITW_T0();')
         emitted = set()
 
         def emit_node(n):
@@ -245,22 +255,30 @@ class Gen:
               (r + 1, len(R['ins']), len(R['searches']), len(R['L2']), len(R['L1'])))
             for n in R['ins']:
                 emit_node(n)
+            P('  CITW_T(%d);' % (4 * r))
             P('  if (lane == 0) {')
             for k, n in enumerate(R['ins']):
-                P('    w.in[%d] = %s;' % (k, self.ref(n)))
+                P('    g_in[wv][%d] = %s;' % (k, self.ref(n)))
             P('  }')
-            P('  citw_search<%d>(w, S[%d], lane);' % (R['maxn'], r))
+            P('  citw_search<%d>(wv, S[%d], lane);' % (R['maxn'], r))
+            P('  CITW_T(%d);' % (4 * r + 1))
             if R['L2']:
-                P('  citw_lookup2d(w, L[%d][0], w.out[%d], lane);' % (r, r))
+                P('  citw_lookup2d(wv, L[%d][0], g_out%d, lane);' % (r, r))
+            P('  CITW_T(%d);' % (4 * r + 2))
             if R['L1']:
-                P('  citw_lookup1d(w, L[%d][1], w.out[%d], lane);' % (r, r))
+                P('  citw_lookup1d(wv, L[%d][1], g_out%d, lane);' % (r, r))
+            P('  CITW_T(%d);' % (4 * r + 3))
             for e in R['L2'] + R['L1']:
                 emitted.add(e['node'])
                 P(self.stmt(e['node']))
         P('  /* ---- derivatives */')
         for i, n in enumerate(self.xdot):
             emit_node(n)
-            P('  XDOT[%d] = %s;' % (i, self.ref(n)))
+        P('  if (lane == 0) {')
+        for i, n in enumerate(self.xdot):
+            P('    g_f[wv][stage][%d] = %s;' % (i, self.ref(n)))
+        P('  }')
+        P('  CITW_T(%d);' % (4 * self.nrounds))
         P('  if (major) {   /* major step only: solver stop time, Derivative-block banks */')
         emit_node(self.stop)
         P('    STOP = %s;' % self.ref(self.stop))
@@ -269,17 +287,25 @@ class Gen:
         P('    if (lane == 0) {')
         for k, n in sorted(self.dw_out.items()):
             if g.nodes[n] != ('in', 'DW', k):
-                P('      w.DW[%d] = %s;' % (k, self.ref(n)))
+                P('      g_dw[wv][%d] = %s;' % (k, self.ref(n)))
         P('    }')
         P('  }')
+        P('  return STOP;')
         P('}')
+        ks = sorted(self.kslot.items(), key=lambda kv: kv[1])
+        P('/* f64 literals of the model, staged into LDS (g_k) so that they are loaded where they are used instead of')
+        P(' * being materialised into scalar registers and kept live across the whole stage loop */')
+        P('enum { citw_%s_NK = %d };' % (V, max(len(ks), 1)))
+        P('static __device__ const double citw_%s_k[%d] = {' % (V, max(len(ks), 1)))
+        P('  ' + ', '.join(hexf(b) for b, _ in ks) if ks else '  0.0')
+        P('};')
         return '\n'.join(out) + '\n'
 
 
 def main():
     variants = [a for a in sys.argv[1:] if not a.startswith('--')] or ['nominal']
     for v in variants:
-        gen = Gen(v, fast_zero='--fast-zero' in sys.argv)
+        gen = Gen(v, fast_zero='--exact-zero' not in sys.argv, lds_consts='--lds-consts' in sys.argv)
         text = gen.emit()
         path = os.path.join(build_dag.ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_wave.inc' % v)
         open(path, 'w').write(text)

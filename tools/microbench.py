@@ -27,7 +27,7 @@ for E, lanes in [(1, 0), (150, 0), (192, 0), (768, 0), (1024, 0), (2048, 0), (40
     res['loop_E%d_L%d' % (E, lanes)] = dict(ms=ms, us_per_step=ms * 1e3 / n, steps_per_s=E * n / (ms * 1e-3))
     if os.environ.get('SERL_PROFILE'):
         import ctypes
-        buf = (ctypes.c_ulonglong * 4)()
+        buf = (ctypes.c_ulonglong * 32)()
         eng.lib.serl_debug_profile(eng.ctx, buf)
         st = max(buf[3], 1)
         res['loop_E%d_L%d' % (E, lanes)]['cycles_per_step'] = dict(actor=buf[0] / st, dyn=buf[1] / st, env=buf[2] / st)
