@@ -41,11 +41,37 @@ void serl_launch_rollout_nominal(const RolloutArgs &a, int grid, hipStream_t str
 void serl_launch_rollout_ice(const RolloutArgs &a, int grid, hipStream_t stream);
 void serl_launch_dyn_nominal(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
 void serl_launch_dyn_ice(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
-void serl_launch_rollout_wave_nominal(const RolloutArgs &a, int grid, hipStream_t stream);
-void serl_launch_dyn_wave_nominal(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
+#define SERL_DECL_WAVE(v)                                                                                     \
+  void serl_launch_rollout_wave_##v(const RolloutArgs &a, int grid, hipStream_t stream);                          \
+  void serl_launch_dyn_wave_##v(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
+SERL_DECL_WAVE(nominal) SERL_DECL_WAVE(ice) SERL_DECL_WAVE(cg_timed) SERL_DECL_WAVE(gust) SERL_DECL_WAVE(test)
 
-// The wave-cooperative kernels (one wavefront per episode, rollout_wave.inc) exist for these code variants.
-static bool serl_has_wave_kernel(int code) { return code == SERL_DYN_NOMINAL; }
+// The wave-cooperative kernels (one wavefront per episode, rollout_wave.inc) exist for every code variant; the
+// lane-per-episode kernels (rollout_variant.inc, lanes_per_wave > 0) only for nominal and ice.
+static bool serl_has_wave_kernel(int code) { return code >= SERL_DYN_NOMINAL && code <= SERL_DYN_TEST; }
+static bool serl_has_lane_kernel(int code) { return code == SERL_DYN_NOMINAL || code == SERL_DYN_ICE; }
+
+static void serl_launch_rollout_wave(int code, const RolloutArgs &a, int grid, hipStream_t stream)
+{
+  switch (code) {
+    case SERL_DYN_NOMINAL: serl_launch_rollout_wave_nominal(a, grid, stream); break;
+    case SERL_DYN_ICE: serl_launch_rollout_wave_ice(a, grid, stream); break;
+    case SERL_DYN_CG_TIMED: serl_launch_rollout_wave_cg_timed(a, grid, stream); break;
+    case SERL_DYN_GUST: serl_launch_rollout_wave_gust(a, grid, stream); break;
+    default: serl_launch_rollout_wave_test(a, grid, stream); break;
+  }
+}
+
+static void serl_launch_dyn_wave(int code, const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream)
+{
+  switch (code) {
+    case SERL_DYN_NOMINAL: serl_launch_dyn_wave_nominal(a, cmds, states, T, grid, stream); break;
+    case SERL_DYN_ICE: serl_launch_dyn_wave_ice(a, cmds, states, T, grid, stream); break;
+    case SERL_DYN_CG_TIMED: serl_launch_dyn_wave_cg_timed(a, cmds, states, T, grid, stream); break;
+    case SERL_DYN_GUST: serl_launch_dyn_wave_gust(a, cmds, states, T, grid, stream); break;
+    default: serl_launch_dyn_wave_test(a, cmds, states, T, grid, stream); break;
+  }
+}
 
 // Wavefronts per workgroup of the wave-cooperative kernels: one per CU while there are no more episodes than CUs,
 // then up to four (one per SIMD) sharing the workgroup's LDS copy of the tables.
@@ -104,7 +130,7 @@ int serl_ctx_load_build(serl_ctx *c, int slot, const serl_build_desc *b)
 {
   if (!c || !b || slot < 0 || slot >= SERL_MAX_SLOTS) return fail(SERL_E_INVALID, "serl_ctx_load_build: bad argument");
   if (!b->ro || !b->t3 || !b->x0 || !b->dw0 || b->n_ro <= 0) return fail(SERL_E_INVALID, "serl_ctx_load_build: NULL table");
-  if (b->code != SERL_DYN_NOMINAL && b->code != SERL_DYN_ICE)
+  if (!serl_has_wave_kernel(b->code))
     return fail(SERL_E_UNSUPPORTED, "serl_ctx_load_build: dynamics code variant not compiled into this library");
   HIP_TRY(hipSetDevice(c->device));
   BuildSlot &s = c->slots[slot];
@@ -163,12 +189,14 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     a.block = 64 * wpb;
     const int grid = (d->n_episodes + wpb - 1) / wpb;
     HIP_TRY(hipEventRecord(c->ev0, stream));
-    serl_launch_rollout_wave_nominal(a, grid, stream);
+    serl_launch_rollout_wave(s.code, a, grid, stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = true;
     return SERL_OK;
   }
+  if (!serl_has_lane_kernel(s.code))
+    return fail(SERL_E_UNSUPPORTED, "serl_rollout: lanes_per_wave > 0 (lane-per-episode kernels) exists only for the nominal and ice code variants");
   if (lanes <= 0) {
     // A wavefront takes the same time per env step whether it carries 1 or 64 episodes, and wavefronts that
     // share a CU slow each other down (measured: profiles/r01_microbench.md), so episodes are spread one
@@ -209,12 +237,14 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
     a.lanes = 1;
     a.block = 64 * wpb;
     HIP_TRY(hipEventRecord(c->ev0, stream));
-    serl_launch_dyn_wave_nominal(a, cmds, states, T, (n_episodes + wpb - 1) / wpb, stream);
+    serl_launch_dyn_wave(s.code, a, cmds, states, T, (n_episodes + wpb - 1) / wpb, stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = true;
     return SERL_OK;
   }
+  if (!serl_has_lane_kernel(s.code))
+    return fail(SERL_E_UNSUPPORTED, "serl_dyn_open_loop: lanes_per_wave > 0 exists only for the nominal and ice code variants");
   int lanes = lanes_per_wave <= 0 ? (n_episodes + 255) / 256 : lanes_per_wave;
   if (lanes > 64) lanes = 64;
   a.lanes = lanes;

@@ -179,7 +179,7 @@ def _as_weights(actors, spec):
 
 def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, smooth_fitness=False,
                  spec: Optional[NetSpec] = None, engine: Optional[RolloutEngine] = None, traces=False,
-                 transitions=False, err0=None, lanes_per_wave=0, need_smoothness=True) -> PopResult:
+                 transitions=False, err0=None, tick0=None, lanes_per_wave=0, need_smoothness=True) -> PopResult:
     """Evaluate a whole population: `num_evals` episodes per member (agent.py:229-256).
 
     actors : sequence of Actor / GeneticAgent, or a packed f32 tensor [pop, P] (then pass `spec`)
@@ -187,6 +187,9 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
              a sequence gives one mode per episode (all must share one dynamics build)
     refs   : f64 [pop*num_evals, T, 3] / [num_evals, T, 3] / [T, 3] radians tables (refsignals.tabulate);
              None = the fixed base evaluation reference for every episode
+    tick0  : i32 [pop*num_evals] model clock each episode starts with (None = 0).  The reference's initialize()
+             does not reset the model clock, so in its sequential loop episode j of a process starts at
+             tick = sum over earlier episodes of (steps + 1); only the time-switched builds (cg-shift, gust) care.
     Episode order is member-major: e = member*num_evals + eval  (the reference's loop nest)."""
     engine = engine or default_engine()
     if spec is None:
@@ -210,7 +213,7 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
     if any(r != builds.NOMINAL_ROW for _, r in resolved):
         faults = np.array([r for _, r in resolved], dtype=np.float64)
     need_actions = traces or smooth_fitness or need_smoothness
-    out = engine.rollout(w, spec, moe, refs, build=blds.pop(), faults=faults, err0=err0, t_max=t_max,
+    out = engine.rollout(w, spec, moe, refs, build=blds.pop(), faults=faults, err0=err0, tick0=tick0, t_max=t_max,
                          traces=need_actions, transitions=transitions, lanes_per_wave=lanes_per_wave)
     ret = out['fitness'].cpu().numpy()
     ls = out['length_steps'].cpu().numpy()
@@ -241,7 +244,8 @@ def make_evaluate(args, *, mode='nominal', t_max=20, ref_fn=None, engine=None, r
     num_frames / gen_frames / num_episodes increments."""
     engine = engine or default_engine()
     counters = counters if counters is not None else {}
-    state = {'err': np.zeros(3)}   # envs/phlabenv.py never clears self.error between episodes
+    # envs/phlabenv.py never clears self.error between episodes, and the native initialize() never resets the model clock
+    state = {'err': np.zeros(3), 'tick': 0}
 
     def evaluate(agent, is_action_noise: bool, store_transition: bool) -> Episode:
         actor = agent.actor if hasattr(agent, 'actor') else agent
@@ -255,9 +259,10 @@ def make_evaluate(args, *, mode='nominal', t_max=20, ref_fn=None, engine=None, r
             noise = np.clip(args.noise_sd * np.random.randn(T, 3), -args.noise_clip, args.noise_clip)[None]
         build, row = builds.resolve_mode(mode)
         out = engine.rollout(pack_population([actor]), spec, [0], ref, build=build,
-                             faults=None if row == builds.NOMINAL_ROW else [row], err0=state['err'][None],
+                             faults=None if row == builds.NOMINAL_ROW else [row], err0=state['err'][None], tick0=[state['tick']],
                              action_noise=noise, t_max=t_max, traces=True, transitions=store_transition)
         n = int(out['length_steps'][0])
+        state['tick'] += abs(n) + 1          # one step in reset() + n env steps
         actions = out['actions'][0, :n].cpu().numpy()
         rewards = out['rewards'][0, :n].cpu().numpy()
         states = out['states'][0, :n].cpu().numpy()

@@ -133,6 +133,9 @@ def parse_statements(lines):
     """lines of a function body -> list of statements"""
     out = []
     for ln in lines:
+        if '__stack_chk_fail' in ln:          # noreturn; the canary compare that guards it folds to false
+            out.append(('return', None))
+            continue
         ln = _CMT.sub('', ln).strip()
         if not ln:
             continue

@@ -78,7 +78,7 @@ class Dag:
         return self.nodes[n][1]
 
     TYPES = dict(true='b', false='b', gt='b', ge='b', lt='b', le='b', eq='b', ne='b', unord='b', bnot='b', band='b',
-                 bor='b', ieq='b', ine='b', bits='i', bitsnot='i', in_i='i', iadd='i', isel='i')
+                 bor='b', ieq='b', ine='b', bits='i', bitsnot='i', in_i='i', iadd='i', isel='i', b2i='i')
 
     def mk(self, op, *a):
         N = self.nodes
@@ -94,6 +94,8 @@ class Dag:
             return self.cf(math.sqrt(self.fval(a[0])))
         if op == 'i2d' and self.is_ci(a[0]):
             return self.cf(float(self.ival(a[0])))
+        if op == 'i2d' and N[a[0]][0] == 'b2i':
+            return self.mk('sel', N[a[0]][1], self.cf(1.0), self.cf(0.0))
         if op in ('fxor', 'fand', 'for', 'fandn') and self.is_cf(a[0]) and self.is_cf(a[1]):
             x, y = N[a[0]][1], N[a[1]][1]
             return self.cfbits({'fxor': x ^ y, 'fand': x & y, 'for': x | y, 'fandn': (~x) & y}[op])
@@ -225,7 +227,7 @@ def p_split_literal(p, q):
     if not p or not q:
         return None
     common = frozenset.intersection(*p)
-    for (c, s) in common:
+    for (c, s) in sorted(common):
         if all((c, not s) in cj for cj in q):
             return (c, s)
     return None
@@ -405,6 +407,8 @@ class SymEx:
             if g.is_ci(a) and g.is_ci(b):
                 if (g.ival(a) & M64) == M64 and g.ival(b) == 0:
                     return g.mk('bits', g.mk('fmask', c))
+                if g.ival(a) == 1 and g.ival(b) == 0:
+                    return g.mk('b2i', c)                       # setcc
                 if c == g.TRUE:
                     return a
                 if c == g.FALSE:
@@ -440,6 +444,13 @@ class SymEx:
                         return g.ci(x >> y)
                     r = {'>': x > y, '>=': x >= y, '<': x < y, '<=': x <= y, '==': x == y, '!=': x != y}[o]
                     return g.TRUE if r else g.FALSE
+                if o in ('&', '|'):
+                    for u, v in ((a, b), (b, a)):
+                        if g.op(u) == 'b2i' and g.is_ci(v):
+                            if o == '&':
+                                return u if (g.ival(v) & 1) else g.ci(0)
+                            if g.ival(v) == 0:
+                                return u
                 if o in ('^', '&', '|'):
                     na, nb = g.nodes[a], g.nodes[b]
                     if o == '&' and na[0] == 'bitsnot':
@@ -684,24 +695,38 @@ class SymEx:
                 succ.append([])
             else:
                 succ.append([i + 1] if i + 1 < nb else [])
-        # topological order (reverse post-order); the CFG must be acyclic
-        order, color = [], [0] * nb
-        stack = [(0, 0)]
-        color[0] = 1
-        while stack:
-            b, k = stack.pop()
-            if k < len(succ[b]):
-                stack.append((b, k + 1))
-                n = succ[b][k]
-                if color[n] == 1:
-                    raise Undefined('cycle in CFG of %s at block %s' % (fname, names[n]))
-                if color[n] == 0:
-                    color[n] = 1
-                    stack.append((n, 0))
-            else:
-                color[b] = 2
-                order.append(b)
-        order.reverse()
+        # topological order (Kahn) over the blocks reachable from the entry; the CFG must be acyclic
+        reach, work = {0}, [0]
+        while work:
+            for n in succ[work.pop()]:
+                if n not in reach:
+                    reach.add(n); work.append(n)
+        indeg = {b: 0 for b in reach}
+        for b in reach:
+            for n in succ[b]:
+                indeg[n] += 1
+        order, ready = [], [0]
+        while ready:
+            ready.sort(reverse=True)
+            b = ready.pop()
+            order.append(b)
+            for n in succ[b]:
+                indeg[n] -= 1
+                if indeg[n] == 0:
+                    ready.append(n)
+        if len(order) != len(reach):
+            done = set(order)
+            left = [b for b in reach if b not in done]
+            # walk predecessors inside the leftover set until a block repeats -> one concrete cycle
+            pred = {b: [p for p in left if b in succ[p]] for b in left}
+            cur, seen = left[0], []
+            while cur not in seen:
+                seen.append(cur)
+                cur = pred[cur][0] if pred[cur] else cur
+                if not pred[seen[-1]]:
+                    break
+            cyc = seen[seen.index(cur):] if cur in seen else seen
+            raise Undefined('cycle in CFG of %s: %s' % (fname, ' <- '.join(str(names[b]) + '#%d' % b for b in cyc[:12])))
         incoming = {0: [(PTRUE, state)]}
         exits = []
         for b in order:
@@ -778,7 +803,7 @@ class SymEx:
     def pred_node(self, p):
         g = self.g
         acc = g.FALSE
-        for cj in p:
+        for cj in sorted(p, key=lambda c: sorted(c)):
             t = g.TRUE
             for (c, s) in sorted(cj):
                 t = g.mk('band', t, c if s else g.mk('bnot', c))
@@ -809,7 +834,7 @@ class SymEx:
                 else:
                     cn = self.pred_node(p1)
             out = {}
-            for key in set(s1) | set(s2):
+            for key in sorted(set(s1) | set(s2), key=str):      # deterministic node numbering
                 a, b = s1.get(key), s2.get(key)
                 if a is None or b is None:
                     if isinstance(key, tuple):
