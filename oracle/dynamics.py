@@ -68,7 +68,7 @@ class CitationDynamics:
     def initialize(self):
         d = self.data
         self.L.cit_reset(self.buf, self.code, d['ro'].ctypes.data_as(_D), d['t3'].ctypes.data_as(_D),
-                         d['x0'].ctypes.data_as(_D), d['dw0'].ctypes.data_as(_D), float(d['dt']))
+                         d['x0'].ctypes.data_as(_D), d['dw0'].ctypes.data_as(_D), float(np.asarray(d['dt']).reshape(-1)[0]))
 
     def step(self, cmd):
         cmd = np.ascontiguousarray(cmd, dtype=np.float64)

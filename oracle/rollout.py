@@ -46,9 +46,9 @@ FAULT_ROWS = {  # envs/{be,jr,sa,se}/citation.py:71-79
 
 def make_build_desc(build):
     data, ent = _dyn.load_build_data(build)
-    bd = BuildDesc(code=_dyn.CODE_IDS[ent['code']], n_ro=len(data['ro']), ro_base=int(data['ro_base']),
+    bd = BuildDesc(code=_dyn.CODE_IDS[ent['code']], n_ro=len(data['ro']), ro_base=int(np.asarray(data['ro_base']).reshape(-1)[0]),
                    ro=data['ro'].ctypes.data_as(_D), t3=data['t3'].ctypes.data_as(_D),
-                   x0=data['x0'].ctypes.data_as(_D), dw0=data['dw0'].ctypes.data_as(_D), dt=float(data['dt']))
+                   x0=data['x0'].ctypes.data_as(_D), dw0=data['dw0'].ctypes.data_as(_D), dt=float(np.asarray(data['dt']).reshape(-1)[0]))
     bd._keep = data
     return bd
 

@@ -72,9 +72,9 @@ class RolloutEngine:
         if key in self.slots:
             return self.slots[key]
         slot = len(self.slots)
-        bd = _capi.BuildDesc(code=builds.CODE_IDS[ent['code']], n_ro=len(data['ro']), ro_base=int(data['ro_base']),
+        bd = _capi.BuildDesc(code=builds.CODE_IDS[ent['code']], n_ro=len(data['ro']), ro_base=int(np.asarray(data['ro_base']).reshape(-1)[0]),
                              ro=data['ro'].ctypes.data, t3=data['t3'].ctypes.data, x0=data['x0'].ctypes.data,
-                             dw0=data['dw0'].ctypes.data, dt=float(data['dt']))
+                             dw0=data['dw0'].ctypes.data, dt=float(np.asarray(data['dt']).reshape(-1)[0]))
         _capi.check(self.lib.serl_ctx_load_build(self.ctx, slot, ctypes.byref(bd)), 'serl_ctx_load_build(%s)' % build)
         self.slots[key] = slot
         return slot
