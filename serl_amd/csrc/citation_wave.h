@@ -27,9 +27,12 @@ struct CitwLookup { uint16_t xrw, nr, xcw, zw, sx, sy, in0, in1, out, p0, p1, p2
 
 // Per-wavefront LDS scratch, one row per wavefront of the workgroup.  Separate objects (not one struct) so that the
 // compiler can tell the blackboards apart: results of look-up round 1 stay loadable across the stores of round 2.
-#define CITW_MAX_WAVES 4
+#ifndef CITW_MAX_WAVES
+#define CITW_MAX_WAVES 4          // wavefronts (episodes) per workgroup; 8 = two per SIMD with 256 registers each
+#endif
 __shared__ double g_in[CITW_MAX_WAVES][32];       // look-up inputs of the current round
 __shared__ int g_sidx[CITW_MAX_WAVES][64];        // interval indices of the current round
+__shared__ double g_m[CITW_MAX_WAVES][64];        // results of the lane-parallel libm calls: [2j] / [2j+1] of call j
 __shared__ double g_out0[CITW_MAX_WAVES][128];    // look-up results of round 1: [0..63] 2-D pass, [64..127] 1-D pass
 __shared__ double g_out1[CITW_MAX_WAVES][128];    // ... round 2
 __shared__ double g_out2[CITW_MAX_WAVES][128];    // ... round 3
@@ -38,6 +41,8 @@ __shared__ double g_f[CITW_MAX_WAVES][6][20];     // ODE5 stage derivatives
 __shared__ double g_xs[CITW_MAX_WAVES][20];       // continuous states X[19] of the current stage (lane i writes state i)
 __shared__ double g_cmd[CITW_MAX_WAVES][12];      // command vector of the current env step
 
+#define CITW_MAX_CONSTS 192
+__shared__ double g_k[CITW_MAX_CONSTS];           // f64 literals of the model (only when generated with --lds-consts)
 __shared__ double g_ro[CITW_RO_LDS_WORDS];
 __shared__ double g_t3[48];
 __shared__ CitwSearch g_S[CITW_MAX_ROUNDS][64];

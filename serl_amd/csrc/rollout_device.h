@@ -144,6 +144,9 @@ static __device__ __forceinline__ float serl_seq_sum(float s, float v, int n)
   return s;
 }
 
+// The network is walked as one sequence of 32-column weight chunks (hidden layers, then the output layer); the
+// loads of chunk i+1 are issued before the multiply-adds of chunk i, so the L2/HBM latency of the weight rows
+// (the wavefront is alone on its SIMD: nothing else hides it) overlaps with arithmetic.
 static __device__ void serl_actor_forward_wave(const serl_rollout_desc &dd, const float *w_generic,
                                                const float obs[7], float act_out[3])
 {
@@ -153,8 +156,35 @@ static __device__ void serl_actor_forward_wave(const serl_rollout_desc &dd, cons
   serl_gptr w = (serl_gptr)w_generic;
   const int lane = threadIdx.x & 63;
   const int i0 = lane < H ? lane : H - 1, i1 = lane + 64 < H ? lane + 64 : H - 1;   // clamped row ids
+  const int io = lane < 3 ? lane : 2;                                                // output-layer row
   const bool two = H > 64;
   const int Ha = H < 64 ? H : 64, Hb = H - Ha;
+  const int nch = (H + 31) >> 5;                       // chunks per row
+  const size_t lstride = (size_t)H * H + 3 * (size_t)H;
+  serl_gptr hid = w + (size_t)H * 7 + H;               // first hidden layer
+  serl_gptr outl = hid + (size_t)L * lstride;          // output layer: Wo[3][H] bo[3]
+  const int nchunks = (L + 1) * nch;
+  float na[32], nb[32];                                // chunk in flight
+  float nbi0 = 0.0f, nbi1 = 0.0f, ngm0 = 0.0f, ngm1 = 0.0f, nbt0 = 0.0f, nbt1 = 0.0f;   // + its layer's bias / gamma / beta
+  // chunk c: layer c / nch (L = output layer), columns 32 * (c % nch) ..
+#define SERL_ISSUE(c)                                                                              \
+  do {                                                                                             \
+    const int l_ = (c) / nch, jc_ = ((c) - l_ * nch) << 5;                                        \
+    if (l_ < L) {                                                                                  \
+      serl_gptr Wl_ = hid + (size_t)l_ * lstride;                                                  \
+      serl_load_chunk(na, Wl_ + (size_t)i0 * H, jc_, H);                                           \
+      if (two) serl_load_chunk(nb, Wl_ + (size_t)i1 * H, jc_, H);                                  \
+      if (jc_ == 0) {                                                                              \
+        serl_gptr bl_ = Wl_ + (size_t)H * H;                                                       \
+        nbi0 = bl_[i0]; ngm0 = bl_[H + i0]; nbt0 = bl_[2 * H + i0];                                \
+        if (two) { nbi1 = bl_[i1]; ngm1 = bl_[H + i1]; nbt1 = bl_[2 * H + i1]; }                   \
+      }                                                                                            \
+    } else {                                                                                       \
+      serl_load_chunk(na, outl + (size_t)io * H, jc_, H);                                          \
+      if (jc_ == 0) nbi0 = (outl + (size_t)3 * H)[io];                                             \
+    }                                                                                              \
+  } while (0)
+  SERL_ISSUE(0);
   float h0a, h0b = 0.0f;
   {
     serl_gptr W = w, b = w + (size_t)H * 7;
@@ -169,44 +199,116 @@ static __device__ void serl_actor_forward_wave(const serl_rollout_desc &dd, cons
     }
     h0a = serl_act(acc0, act);
     if (two) h0b = serl_act(acc1, act);
-    w = b + H;
   }
-  for (int l = 0; l < L; ++l) {
-    serl_gptr Wl = w, bl = w + (size_t)H * H, g = bl + H, be = g + H;
-    float acc0 = bl[i0], acc1 = bl[i1];
-    serl_gptr r0 = Wl + (size_t)i0 * H, r1 = Wl + (size_t)i1 * H;
-    for (int jc = 0; jc < H; jc += 32) {
-      float wa[32], wb[32];
-      serl_load_chunk(wa, r0, jc, H);
-      if (two) serl_load_chunk(wb, r1, jc, H);
+  float acc0 = 0.0f, acc1 = 0.0f, gm0 = 0.0f, gm1 = 0.0f, bt0 = 0.0f, bt1 = 0.0f;
+  for (int c = 0; c < nchunks; ++c) {
+    const int l = c / nch, jc = (c - l * nch) << 5;
+    float wa[32], wb[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { wa[q] = na[q]; wb[q] = nb[q]; }
+    if (jc == 0) { acc0 = nbi0; acc1 = nbi1; gm0 = ngm0; gm1 = ngm1; bt0 = nbt0; bt1 = nbt1; }
+    if (c + 1 < nchunks) SERL_ISSUE(c + 1);
+    if (l < L) {
       const float hsrc = (jc < 64) ? h0a : h0b;
       acc0 = serl_mac_chunk(acc0, wa, hsrc, jc & 63, jc, H);
       if (two) acc1 = serl_mac_chunk(acc1, wb, hsrc, jc & 63, jc, H);
+      if (jc + 32 >= H) {      // row complete: LayerNorm + activation
+        float mean = serl_seq_sum(0.0f, acc0, Ha);
+        if (two) mean = serl_seq_sum(mean, acc1, Hb);
+        mean = mean / (float)H;
+        const float d0 = acc0 - mean, d1 = acc1 - mean;
+        float var = serl_seq_sum(0.0f, d0 * d0, Ha);
+        if (two) var = serl_seq_sum(var, d1 * d1, Hb);
+        const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
+        h0a = serl_act(gm0 * d0 / den + bt0, act);
+        if (two) h0b = serl_act(gm1 * d1 / den + bt1, act);
+      }
+    } else {
+      acc0 = serl_mac_chunk(acc0, wa, (jc < 64) ? h0a : h0b, jc & 63, jc, H);
+      if (jc + 32 >= H) {
+        const float t = det_tanhf(acc0);
+        for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, i);
+      }
     }
-    float mean = serl_seq_sum(0.0f, acc0, Ha);
-    if (two) mean = serl_seq_sum(mean, acc1, Hb);
-    mean = mean / (float)H;
-    const float d0 = acc0 - mean, d1 = acc1 - mean;
-    float var = serl_seq_sum(0.0f, d0 * d0, Ha);
-    if (two) var = serl_seq_sum(var, d1 * d1, Hb);
-    const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
-    h0a = serl_act(g[i0] * d0 / den + be[i0], act);
-    if (two) h0b = serl_act(g[i1] * d1 / den + be[i1], act);
-    w = be + H;
   }
+#undef SERL_ISSUE
+}
+
+// Shape-specialised forward for H <= 64 (one row per lane, H a multiple of 4): every loop bound is a compile-time
+// constant, a whole weight row (H floats, dwordx4 loads) plus its bias / gamma / beta are fetched one layer ahead of
+// the arithmetic.  Same operation order as serl_actor_forward_wave (= the oracle's).
+template <int H>
+static __device__ void serl_actor_forward_small(const serl_rollout_desc &dd, const float *w_generic, const float obs[7],
+                                                float act_out[3])
+{
+  static_assert(H % 4 == 0 && H <= 64, "one row per lane");
+  const int L = __builtin_amdgcn_readfirstlane(dd.num_layers), act = __builtin_amdgcn_readfirstlane(dd.activation);
+  serl_gptr w = (serl_gptr)w_generic;
+  const int lane = threadIdx.x & 63;
+  const int i0 = lane < H ? lane : H - 1, io = lane < 3 ? lane : 2;
+  constexpr size_t lstride = (size_t)H * H + 3 * (size_t)H;
+  serl_gptr hid = w + (size_t)H * 7 + H, outl = hid + (size_t)L * lstride;
+  float nrow[H], nbi, ngm = 0.0f, nbt = 0.0f;
+  auto issue = [&](int l) {
+    serl_gptr row = l < L ? hid + (size_t)l * lstride + (size_t)i0 * H : outl + (size_t)io * H;
+#pragma unroll
+    for (int q = 0; q < H / 4; ++q) {
+      const serl_v4f v = *(serl_gptr4)(row + 4 * q);
+      nrow[4 * q] = v.x; nrow[4 * q + 1] = v.y; nrow[4 * q + 2] = v.z; nrow[4 * q + 3] = v.w;
+    }
+    if (l < L) {
+      serl_gptr bl = hid + (size_t)l * lstride + (size_t)H * H;
+      nbi = bl[i0]; ngm = bl[H + i0]; nbt = bl[2 * H + i0];
+    } else {
+      nbi = (outl + (size_t)3 * H)[io];
+    }
+  };
+  issue(0);
+  float h;
   {
-    serl_gptr Wo = w, bo = w + (size_t)3 * H;
-    const int io = lane < 3 ? lane : 2;
-    float acc = bo[io];
-    serl_gptr ro_ = Wo + (size_t)io * H;
-    for (int jc = 0; jc < H; jc += 32) {
-      float wa[32];
-      serl_load_chunk(wa, ro_, jc, H);
-      acc = serl_mac_chunk(acc, wa, (jc < 64) ? h0a : h0b, jc & 63, jc, H);
-    }
-    const float t = det_tanhf(acc);
-    for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, i);
+    serl_gptr W = w + (size_t)i0 * 7, b = w + (size_t)H * 7;
+    float acc = b[i0], w0[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) w0[j] = W[j];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc = acc + w0[j] * obs[j];
+    h = serl_act(acc, act);
   }
+  for (int l = 0; l <= L; ++l) {
+    float row[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) row[j] = nrow[j];
+    float acc = nbi;
+    const float gm = ngm, bt = nbt;
+    if (l < L) issue(l + 1);
+#pragma unroll
+    for (int j = 0; j < H; ++j) acc = acc + row[j] * serl_bcast(h, j);
+    if (l < L) {
+      float mean = 0.0f;
+#pragma unroll
+      for (int j = 0; j < H; ++j) mean = mean + serl_bcast(acc, j);
+      mean = mean / (float)H;
+      const float d = acc - mean, dd2 = d * d;
+      float var = 0.0f;
+#pragma unroll
+      for (int j = 0; j < H; ++j) var = var + serl_bcast(dd2, j);
+      const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
+      h = serl_act(gm * d / den + bt, act);
+    } else {
+      const float t = det_tanhf(acc);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, i);
+    }
+  }
+}
+
+static __device__ __forceinline__ void serl_actor_forward(const serl_rollout_desc &dd, const float *w, const float obs[7],
+                                                          float act_out[3])
+{
+  const int H = __builtin_amdgcn_readfirstlane(dd.hidden);
+  if (H == 32) serl_actor_forward_small<32>(dd, w, obs, act_out);
+  else if (H == 64) serl_actor_forward_small<64>(dd, w, obs, act_out);
+  else serl_actor_forward_wave(dd, w, obs, act_out);
 }
 
 static __device__ __forceinline__ double serl_clip(double v, double lo, double hi)

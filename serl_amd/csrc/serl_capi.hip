@@ -77,8 +77,8 @@ static void serl_launch_dyn_wave(int code, const RolloutArgs &a, const double *c
 // then up to four (one per SIMD) sharing the workgroup's LDS copy of the tables.
 static int serl_wave_kernel_waves_per_block(int episodes)
 {
-  const char *env = getenv("SERL_WAVES_PER_BLOCK");
-  if (env && atoi(env) >= 1 && atoi(env) <= 4) return atoi(env);
+  const char *env = getenv("SERL_WAVES_PER_BLOCK");     // (8 only with a library built with -DCITW_MAX_WAVES=8)
+  if (env && atoi(env) >= 1 && atoi(env) <= 8) return atoi(env);
   int w = (episodes + 255) / 256;
   return w < 1 ? 1 : (w > 4 ? 4 : w);
 }

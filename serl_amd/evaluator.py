@@ -184,7 +184,7 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
 
     actors : sequence of Actor / GeneticAgent, or a packed f32 tensor [pop, P] (then pass `spec`)
     mode   : PH-LAB mode or env name ('nominal', 'be', 'PHlab_attitude_ice', ...; envs/phlabenv.py:99-172);
-             a sequence gives one mode per episode (all must share one dynamics build)
+             a sequence gives one mode per episode (mixed-fault sweeps: one kernel launch per dynamics build)
     refs   : f64 [pop*num_evals, T, 3] / [num_evals, T, 3] / [T, 3] radians tables (refsignals.tabulate);
              None = the fixed base evaluation reference for every episode
     tick0  : i32 [pop*num_evals] model clock each episode starts with (None = 0).  The reference's initialize()
@@ -206,15 +206,38 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
     modes = [mode] * E if isinstance(mode, str) else list(mode)
     assert len(modes) == E
     resolved = [builds.resolve_mode(m) for m in modes]
-    blds = {b for b, _ in resolved}
-    if len(blds) != 1:
-        raise ValueError('one evaluate_pop call runs one dynamics build; got %s (split the population by build)' % sorted(blds))
-    faults = None
-    if any(r != builds.NOMINAL_ROW for _, r in resolved):
-        faults = np.array([r for _, r in resolved], dtype=np.float64)
     need_actions = traces or smooth_fitness or need_smoothness
-    out = engine.rollout(w, spec, moe, refs, build=blds.pop(), faults=faults, err0=err0, tick0=tick0, t_max=t_max,
-                         traces=need_actions, transitions=transitions, lanes_per_wave=lanes_per_wave)
+    tick0 = None if tick0 is None else np.asarray(tick0, dtype=np.int32).reshape(E)
+    err0 = None if err0 is None else np.asarray(err0, dtype=np.float64).reshape(E, 3)
+    # one kernel launch per dynamics build (be/jr/sa/se share the nominal build as per-episode fault rows; cg, ice,
+    # cg-shift ... are builds of their own); launches are stream-ordered and their results scattered back
+    groups = {}
+    for e, (b, _) in enumerate(resolved):
+        groups.setdefault(b, []).append(e)
+    out, kernel_ms = None, 0.0
+    for b, idx in groups.items():
+        idx = np.asarray(idx)
+        rows = [resolved[e][1] for e in idx]
+        faults = np.array(rows, dtype=np.float64) if any(r != builds.NOMINAL_ROW for r in rows) else None
+        whole = len(idx) == E
+        o = engine.rollout(w, spec, moe[idx], refs if (whole or refs.dim() == 2) else refs[torch.as_tensor(idx)], build=b,
+                           faults=faults, err0=None if err0 is None else err0[idx],
+                           tick0=None if tick0 is None else tick0[idx], t_max=t_max,
+                           traces=need_actions, transitions=transitions, lanes_per_wave=lanes_per_wave)
+        kernel_ms += engine.last_kernel_ms
+        if whole:
+            out = o
+            break
+        if out is None:
+            out = {}
+        ti = torch.as_tensor(idx, device=o['fitness'].device)
+        for k, v in o.items():
+            if not torch.is_tensor(v):
+                continue
+            if k not in out:
+                out[k] = torch.zeros((E,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+            out[k][ti] = v
+    engine.last_kernel_ms = kernel_ms
     ret = out['fitness'].cpu().numpy()
     ls = out['length_steps'].cpu().numpy()
     if need_actions:

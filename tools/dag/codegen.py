@@ -35,8 +35,10 @@ def hexf(bits):
 
 
 class Gen:
-    def __init__(self, variant, fast_zero=True, lds_consts=False):
+    def __init__(self, variant, fast_zero=True, lds_consts=False, lane_libm=True, lazy_loads=False):
         self.variant = variant
+        self.lazy_loads = lazy_loads
+        self.lane_libm = lane_libm
         self.lds_consts = lds_consts
         self.kslot = {}
         self.g, self.res, self.datas = build_dag.build(variant, fast_zero=fast_zero)
@@ -90,6 +92,34 @@ class Gen:
             assert len(L2) <= 64 and len(L1) <= 64, (len(L2), len(L1))
             self.rounds.append(dict(ins=ins, searches=searches, L2=L2, L1=L1,
                                     maxn=max(s[1] for s in searches)))
+        # ---- libm calls that depend on the states only (no look-up / libm ancestor): one lane per call
+        LIBM = ('sc_sin', 'sc_cos', 'sin', 'cos', 'tan', 'exp', 'log10', 'log', 'atan', 'pow')
+        has_anc = {}
+        for n in self.order:
+            has_anc[n] = any(has_anc[c] or g.nodes[c][0] in LIBM or g.nodes[c][0] in LOOKUPS
+                             for c in build_dag.children(g, n))
+        calls = {}      # (fn, arg node, param bits) -> {'sin': node, 'cos': node} / {'out': node}
+        for n in self.order:
+            t = g.nodes[n]
+            if t[0] not in LIBM or not self.lane_libm:
+                continue
+            if has_anc[n] or (t[0] == 'pow' and not g.is_cf(t[2])):
+                continue
+            if t[0] in ('sc_sin', 'sin'):
+                calls.setdefault(('sincos', t[1], 0), {})['r0'] = n
+            elif t[0] in ('sc_cos', 'cos'):
+                calls.setdefault(('sincos', t[1], 0), {})['r1'] = n
+            elif t[0] == 'pow':
+                calls.setdefault(('pow', t[1], g.nodes[t[2]][1]), {})['r0'] = n
+            else:
+                calls.setdefault((t[0], t[1], 0), {})['r0'] = n
+        order_fn = ['sincos', 'tan', 'exp', 'log10', 'log', 'atan', 'pow']
+        self.libm_calls = sorted(calls.items(), key=lambda kv: (order_fn.index(kv[0][0]), kv[0][1], kv[0][2]))
+        assert len(self.libm_calls) <= 32
+        self.libm_slot = {}
+        for j, (key, outs) in enumerate(self.libm_calls):
+            for which, node in outs.items():
+                self.libm_slot[node] = 2 * j + (0 if which == 'r0' else 1)
         self.outslot = {}
         for r, R in enumerate(self.rounds):
             for k, e in enumerate(R['L2']):
@@ -139,6 +169,8 @@ class Gen:
             return None
         ty = {'f': 'const double', 'b': 'const bool', 'i': 'const long long'}[g.ty[n]]
         name = R(n)
+        if n in self.libm_slot:
+            return '  %s %s = g_m[wv][%d];' % (ty, name, self.libm_slot[n])
         if op in self.BIN:
             e = '%s %s %s' % (R(t[1]), self.BIN[op], R(t[2]))
         elif op == 'neg':
@@ -225,6 +257,7 @@ class Gen:
         P('  const int lane = threadIdx.x & 63;')
         P('  CITW_T0();')
         emitted = set()
+        done_rounds = set()
 
         def emit_node(n):
             # iterative post-order over un-emitted children
@@ -236,6 +269,8 @@ class Gen:
                 if done:
                     emitted.add(m)
                     t = g.nodes[m]
+                    if t[0] in LOOKUPS:
+                        assert self.outslot[m][0] in done_rounds, 'look-up result used before its round'
                     if t[0] in ('sc_sin', 'sc_cos'):
                         s_, c_ = g.memo.get(('sc_sin', t[1])), g.memo.get(('sc_cos', t[1]))
                         P('  double v%d, v%d; sincos(%s, &v%d, &v%d);' % (s_, c_, self.ref(t[1]), s_, c_))
@@ -246,10 +281,42 @@ class Gen:
                         P(s)
                     continue
                 stack.append((m, True))
+                if g.nodes[m][0] in LOOKUPS or m in self.libm_slot:
+                    continue          # value comes from LDS; its inputs were consumed by the lane phase
                 for c in build_dag.children(g, m):
                     if c not in emitted:
                         stack.append((c, False))
 
+        if self.libm_calls:
+            P('  /* ---- libm calls that depend on the states only: one lane per call (the branches of one function run together) */')
+            for (fn, arg, prm), outs in self.libm_calls:
+                emit_node(arg)
+            P('  if (lane == 0) {')
+            for j, ((fn, arg, prm), outs) in enumerate(self.libm_calls):
+                P('    g_in[wv][%d] = %s;' % (j, self.ref(arg)))
+            P('  }')
+            P('  {')
+            P('    const double a_ = g_in[wv][lane < %d ? lane : 0];' % len(self.libm_calls))
+            P('    double r0_ = 0.0, r1_ = 0.0;')
+            j = 0
+            first = True
+            while j < len(self.libm_calls):
+                fn, prm = self.libm_calls[j][0][0], self.libm_calls[j][0][2]
+                k = j
+                while k < len(self.libm_calls) and self.libm_calls[k][0][0] == fn and (fn != 'pow' or self.libm_calls[k][0][2] == prm):
+                    k += 1
+                cond = '(lane >= %d && lane < %d)' % (j, k) if k - j > 1 else '(lane == %d)' % j
+                call = {'sincos': 'sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = pow(a_, %s)' % hexf(prm)}.get(fn, 'r0_ = %s(a_)' % fn)
+                P('    %sif %s { %s; }' % ('' if first else 'else ', cond, call))
+                first = False
+                j = k
+            P('    if (lane < %d) { g_m[wv][2 * lane] = r0_; g_m[wv][2 * lane + 1] = r1_; }' % len(self.libm_calls))
+            P('  }')
+            if not self.lazy_loads:
+                for (fn, arg, prm), outs in self.libm_calls:
+                    for node in outs.values():
+                        emitted.add(node)
+                        P(self.stmt(node))
         for r, R in enumerate(self.rounds):
             P('  /* ---- look-up round %d: %d inputs, %d index searches, %d 2-D + %d 1-D tables */' %
               (r + 1, len(R['ins']), len(R['searches']), len(R['L2']), len(R['L1'])))
@@ -268,9 +335,11 @@ class Gen:
             if R['L1']:
                 P('  citw_lookup1d(wv, L[%d][1], g_out%d, lane);' % (r, r))
             P('  CITW_T(%d);' % (4 * r + 3))
-            for e in R['L2'] + R['L1']:
-                emitted.add(e['node'])
-                P(self.stmt(e['node']))
+            done_rounds.add(r)
+            if not self.lazy_loads:
+                for e in R['L2'] + R['L1']:
+                    emitted.add(e['node'])
+                    P(self.stmt(e['node']))
         P('  /* ---- derivatives */')
         for i, n in enumerate(self.xdot):
             emit_node(n)
@@ -305,7 +374,8 @@ class Gen:
 def main():
     variants = [a for a in sys.argv[1:] if not a.startswith('--')] or ['nominal']
     for v in variants:
-        gen = Gen(v, fast_zero='--exact-zero' not in sys.argv, lds_consts='--lds-consts' in sys.argv)
+        gen = Gen(v, fast_zero='--exact-zero' not in sys.argv, lds_consts='--lds-consts' in sys.argv,
+                  lane_libm='--uniform-libm' not in sys.argv, lazy_loads='--lazy-loads' in sys.argv)
         text = gen.emit()
         path = os.path.join(build_dag.ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_wave.inc' % v)
         open(path, 'w').write(text)
