@@ -1,0 +1,98 @@
+"""Host-side mirror of the reference interface (serl_amd/*.py) and the C-ABI surface, without a GPU:
+  * the library loads and exports every entry point include/serl_amd.h declares (no compute calls);
+  * the product refuses to run without a GPU instead of falling back to a CPU path;
+  * Actor / NetSpec packing is the layout the kernel and the oracle read (shipped checkpoints);
+  * metrics (calc_smoothness on torch.fft, calc_nMAE) against the reference's numbers in the golden files;
+  * reference-signal tabulation against the shipped trajectories; PH-LAB mode names."""
+import os, re, ctypes
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from serl_amd import build, _capi
+    lib_path = build.build()
+    hdr = open(os.path.join(ROOT, 'include', 'serl_amd.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    names = sorted(set(re.findall(r'\b(serl_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(names) >= 12, names
+    L = ctypes.CDLL(lib_path)
+    for n in names:
+        assert hasattr(L, n), 'libserl_amd.so does not export %s' % n
+    assert set(_capi.EXPORTS) <= set(names)
+    L.serl_abi_version.restype = ctypes.c_int
+    assert L.serl_abi_version() == int(re.search(r'#define SERL_ABI_VERSION (\d+)', hdr).group(1))
+    L.serl_param_count.restype = ctypes.c_int
+    assert L.serl_param_count(7, 32, 3, 3) == 3715 and L.serl_param_count(7, 72, 3, 3) == 16995
+
+
+def test_no_cpu_fallback_in_the_product():
+    import serl_amd
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(RuntimeError):
+        serl_amd.RolloutEngine(0)
+    src = ''.join(open(os.path.join(ROOT, 'serl_amd', f)).read() for f in os.listdir(os.path.join(ROOT, 'serl_amd'))
+                  if f.endswith('.py'))
+    assert 'import oracle' not in src and 'from oracle' not in src, 'the product must not touch the oracle'
+
+
+def test_actor_packing_matches_the_oracle_layout(golden):
+    import serl_amd
+    from serl_amd.actor import NetSpec
+    spec = NetSpec(7, 3, 32, 3, 'tanh')
+    assert spec.param_count == 3715 and spec.row_stride % 4 == 0
+    row = golden('actors')['serl50'][18]
+    import argparse
+    args = argparse.Namespace(hidden_size=32, num_layers=3, activation_actor='tanh', state_dim=7, action_dim=3,
+                              device=torch.device('cpu'))
+    a = serl_amd.Actor(args)
+    sd, off = {}, 0
+    for name, o, shape in spec.param_layout():
+        n = int(np.prod(shape))
+        sd[name] = torch.from_numpy(row[o:o + n].reshape(shape).copy())
+    a.load_state_dict(sd)
+    packed = serl_amd.pack_population([a])
+    np.testing.assert_array_equal(packed[0, :3715].numpy(), row)
+    # forward of the torch interface module == golden samples of the reference's own Actor
+    g = golden('pop_serl50')
+    obs = torch.from_numpy(g['obs_samples'].astype(np.float32))
+    with torch.no_grad():
+        out = a(obs).numpy()
+    np.testing.assert_allclose(out, g['act_samples'][18], atol=5e-6)
+    # GA genome = 2-D weights only (genetic_agent.py:131-141)
+    assert sum(n for _, n in spec.genome_segments()) == 7 * 32 + 3 * 32 * 32 + 3 * 32
+
+
+def test_metrics_against_reference_numbers(golden):
+    from serl_amd import metrics
+    from oracle import rollout as R
+    NET = dict(state_dim=7, action_dim=3, hidden=32, num_layers=3, activation='tanh')
+    w = golden('actors')['serl50'][[18, 0]]
+    ref = golden('ref_base')['ref']
+    o = R.rollout(w, NET, [0, 1], ref, t_max=80, traces=True)
+    sm = metrics.calc_smoothness(torch.from_numpy(o['actions']), torch.from_numpy(o['length_steps'])).numpy()
+    g = golden('pop_serl50')
+    np.testing.assert_allclose(sm, g['smoothness'][[18, 0]], rtol=1e-4)      # the reference's scipy FFT numbers
+    # calc_nMAE: closed form on a synthetic error history (base/core/utils.py:39-58)
+    err = np.stack([np.full(100, 0.01), np.full(100, -0.02), np.linspace(-0.001, 0.001, 100)], 1)
+    want = np.mean(np.abs(err).mean(0) / np.array([np.deg2rad(20), np.deg2rad(20), 3.14159 / 180])) * 100
+    assert abs(metrics.calc_nMAE(err) - want) < 1e-12
+
+
+def test_reference_tables_and_mode_names(golden):
+    from serl_amd import refsignals, builds
+    ref = refsignals.tabulate(*refsignals.base_reference(80), 80)
+    np.testing.assert_allclose(ref, golden('ref_base')['ref'], atol=2e-15)
+    assert ref.shape == (8001, 3)
+    t = refsignals.env_times(8001)
+    assert t[0] == 0.0 and t[-1] >= 80.0 and t[-2] < 80.0          # accumulated t += 0.01 reaches t_max at k = 8000
+    for mode, build in [('nominal', 'h2000_v90'), ('PHlab_attitude_be', 'h2000_v90'), ('ice', 'ice'), ('cg', 'cg'),
+                        ('cg-for', 'cg_for'), ('cg-shift', 'cg_timed'), ('high-q', 'h2000_v150'), ('low-q', 'h10000_v90')]:
+        assert builds.resolve_mode(mode)[0] == build, mode
+    assert builds.resolve_mode('be')[1][0] == 0.3                      # envs/be/citation.py:73  cmd[0] *= 0.3
+    with pytest.raises(ValueError):
+        builds.resolve_mode('no-such-mode')
