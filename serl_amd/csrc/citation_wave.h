@@ -22,7 +22,8 @@
 #define CITW_MAX_ROUNDS 3
 #define CITW_RO_LDS_WORDS 12040
 
-struct CitwSearch { uint16_t xw, n, in, pad; };                                 // 8 B
+struct CitwSearch { uint16_t row, n, in, pad; };                                // 8 B: row of g_bp, entries, input slot
+struct CitwBpVec { uint16_t xw, n; };                                           // a distinct breakpoint vector: word offset in g_ro, entries
 struct CitwLookup { uint16_t xrw, nr, xcw, zw, sx, sy, in0, in1, out, p0, p1, p2; };   // 24 B; 1-D: x = xrw, y = zw
 
 // Per-wavefront LDS scratch, one row per wavefront of the workgroup.  Separate objects (not one struct) so that the
@@ -40,11 +41,15 @@ __shared__ double g_dw[CITW_MAX_WAVES][32];       // Derivative-block banks (rtD
 __shared__ double g_f[CITW_MAX_WAVES][6][20];     // ODE5 stage derivatives
 __shared__ double g_xs[CITW_MAX_WAVES][20];       // continuous states X[19] of the current stage (lane i writes state i)
 __shared__ double g_cmd[CITW_MAX_WAVES][12];      // command vector of the current env step
+__shared__ double g_x[256];                       // team kernels: values wave 1 computes for wave 0 (rollout_team.inc)
 
 #define CITW_MAX_CONSTS 192
 __shared__ double g_k[CITW_MAX_CONSTS];           // f64 literals of the model (only when generated with --lds-consts)
 __shared__ double g_ro[CITW_RO_LDS_WORDS];
 __shared__ double g_t3[48];
+#define CITW_MAX_BPVEC 48
+#define CITW_BP_PAD 24
+__shared__ double g_bp[CITW_MAX_BPVEC][CITW_BP_PAD];   // the distinct breakpoint vectors, padded with +inf (index search without bounds tests)
 __shared__ CitwSearch g_S[CITW_MAX_ROUNDS][64];
 __shared__ CitwLookup g_L[CITW_MAX_ROUNDS][2][64];
 
@@ -56,9 +61,15 @@ __shared__ unsigned long long g_tlast;
 #define CITW_T0() do { if (blockIdx.x == 0 && threadIdx.x == 0) g_tlast = __builtin_readcyclecounter(); } while (0)
 #define CITW_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
                          g_prof[(k)] += t_ - g_tlast; g_tlast = t_; } } while (0)
+__shared__ unsigned long long g_tlast1;       // same for wave 1 of the team kernels
+#define CITW_U0() do { if (blockIdx.x == 0 && threadIdx.x == 64) g_tlast1 = __builtin_readcyclecounter(); } while (0)
+#define CITW_U(k) do { if (blockIdx.x == 0 && threadIdx.x == 64) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+                         g_prof[(k)] += t_ - g_tlast1; g_tlast1 = t_; } } while (0)
 #else
 #define CITW_T0() ((void)0)
 #define CITW_T(k) ((void)0)
+#define CITW_U0() ((void)0)
+#define CITW_U(k) ((void)0)
 #endif
 
 static __device__ __forceinline__ unsigned long long citw_d2u(double d) { return (unsigned long long)__double_as_longlong(d); }
@@ -66,21 +77,24 @@ static __device__ __forceinline__ double citw_u2d(unsigned long long u) { return
 
 // interval index (rt_GetLookupIndex semantics):
 //   u <= x[0] -> 0 ; u >= x[n-1] -> n-2 ; u < 0: x[i] <= u < x[i+1] ; u >= 0: x[i] < u <= x[i+1]
+// The vectors are strictly increasing, so  lt = #{x_i < u}  is a position and  le = #{x_i <= u} = lt + (x[lt] == u);
+// rows of g_bp are padded with +inf, which no comparison below counts for finite u (and the clamp absorbs u = +inf).
 template <int MAXN>
 static __device__ __forceinline__ void citw_search(const int wv, const CitwSearch *S, int lane)
 {
+  typedef double v2d __attribute__((ext_vector_type(2)));
   const CitwSearch d = S[lane];
   const double u = g_in[wv][d.in];
-  const double *x = g_ro + d.xw;
+  const double *x = g_bp[d.row];
   const int n = d.n;
-  int lt = 0, le = 0;
+  int lt = 0;
 #pragma unroll
-  for (int i = 0; i < MAXN; ++i) {
-    const double v = x[i < n ? i : 0];
-    const bool ok = i < n;
-    lt += (ok && v < u) ? 1 : 0;
-    le += (ok && v <= u) ? 1 : 0;
+  for (int i = 0; i < ((MAXN + 1) & ~1); i += 2) {
+    const v2d v = *(const v2d *)(x + i);
+    lt += (v.x < u) ? 1 : 0;
+    lt += (v.y < u) ? 1 : 0;
   }
+  const int le = lt + ((x[lt < CITW_BP_PAD - 1 ? lt : CITW_BP_PAD - 1] == u) ? 1 : 0);
   int idx = ((u < 0.0) ? le : lt) - 1;
   idx = idx < 0 ? 0 : idx;
   idx = idx > n - 2 ? n - 2 : idx;

@@ -1,0 +1,9 @@
+// rollout_team_nominal.hip -- two-wavefront-per-episode rollout kernels for the 'nominal' dynamics code variant
+// (rollout_team.inc, gen/citation_nominal_team.inc): the latency-bound regime, fewer episodes than CUs.
+#include "citation_wave.h"
+#include "rollout_device.h"
+#include "gen/citation_nominal_wave.inc"   // look-up descriptor tables (shared with the one-wave kernels)
+#include "gen/citation_nominal_team.inc"
+#define VARIANT nominal
+#include "rollout_team.inc"
+#undef VARIANT

@@ -46,6 +46,19 @@ void serl_launch_dyn_ice(const RolloutArgs &a, const double *cmds, double *state
   void serl_launch_dyn_wave_##v(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
 SERL_DECL_WAVE(nominal) SERL_DECL_WAVE(ice) SERL_DECL_WAVE(cg_timed) SERL_DECL_WAVE(gust) SERL_DECL_WAVE(test)
 
+// two wavefronts per episode (rollout_team.inc): the latency-bound regime, fewer episodes than CUs
+void serl_launch_rollout_team_nominal(const RolloutArgs &a, int grid, hipStream_t stream);
+void serl_launch_dyn_team_nominal(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
+static bool serl_has_team_kernel(int code) { return code == SERL_DYN_NOMINAL; }
+// SERL_TEAM=0 never, =1 always (when the variant has it); default: when every episode can have a CU of its own
+static bool serl_use_team(int code, int episodes)
+{
+  if (!serl_has_team_kernel(code)) return false;
+  const char *env = getenv("SERL_TEAM");
+  if (env) return atoi(env) != 0;
+  return false;
+}
+
 // The wave-cooperative kernels (one wavefront per episode, rollout_wave.inc) exist for every code variant; the
 // lane-per-episode kernels (rollout_variant.inc, lanes_per_wave > 0) only for nominal and ice.
 static bool serl_has_wave_kernel(int code) { return code >= SERL_DYN_NOMINAL && code <= SERL_DYN_TEST; }
@@ -182,6 +195,16 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     a.prof = c->prof;
   }
   int lanes = d->lanes_per_wave;
+  if (lanes <= 0 && serl_use_team(s.code, d->n_episodes)) {
+    a.lanes = 1;
+    a.block = 128;
+    HIP_TRY(hipEventRecord(c->ev0, stream));
+    serl_launch_rollout_team_nominal(a, d->n_episodes, stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, stream));
+    c->timed = true;
+    return SERL_OK;
+  }
   if (lanes <= 0 && serl_has_wave_kernel(s.code)) {
     // default: one wavefront per episode (model glue wave-uniform, look-ups / actor rows / ODE5 states per lane)
     const int wpb = serl_wave_kernel_waves_per_block(d->n_episodes);
@@ -232,6 +255,16 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
   a.ro = s.blob; a.t3 = s.blob + s.n_ro; a.x0 = a.t3 + 46; a.dw0 = a.x0 + 19;
   a.dyn_dt = s.dt;
   hipStream_t stream = (hipStream_t)stream_;
+  if (lanes_per_wave <= 0 && serl_use_team(s.code, n_episodes)) {
+    a.lanes = 1;
+    a.block = 128;
+    HIP_TRY(hipEventRecord(c->ev0, stream));
+    serl_launch_dyn_team_nominal(a, cmds, states, T, n_episodes, stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, stream));
+    c->timed = true;
+    return SERL_OK;
+  }
   if (lanes_per_wave <= 0 && serl_has_wave_kernel(s.code)) {
     const int wpb = serl_wave_kernel_waves_per_block(n_episodes);
     a.lanes = 1;

@@ -120,6 +120,13 @@ class Gen:
         for j, (key, outs) in enumerate(self.libm_calls):
             for which, node in outs.items():
                 self.libm_slot[node] = 2 * j + (0 if which == 'r0' else 1)
+        # distinct breakpoint vectors over all rounds -> rows of g_bp
+        self.bpvec = []
+        for R in self.rounds:
+            for (xa, n, slot) in R['searches']:
+                if (xa, n) not in self.bpvec:
+                    self.bpvec.append((xa, n))
+        assert len(self.bpvec) <= 48 and max(n for _, n in self.bpvec) <= 23
         self.outslot = {}
         for r, R in enumerate(self.rounds):
             for k, e in enumerate(R['L2']):
@@ -145,6 +152,9 @@ class Gen:
         if op == 'false':
             return 'false'
         if op == 'in':
+            ov = getattr(self, 'in_override', None)
+            if ov and n in ov:
+                return ov[n]
             if t[1] == 'RO':
                 return 'g_ro[%d]' % ((t[2] >> 3) - self.low)
             if t[1] == 'T':
@@ -231,10 +241,12 @@ class Gen:
         # ---- descriptor tables
         P('static __device__ const CitwSearch citw_%s_search[%d][64] = {' % (V, self.nrounds))
         for R in self.rounds:
-            rows = ['{%d, %d, %d, 0}' % ((s[0] >> 3) - lw, s[1], s[2]) for s in R['searches']]
+            rows = ['{%d, %d, %d, 0}' % (self.bpvec.index((s[0], s[1])), s[1], s[2]) for s in R['searches']]
             rows += ['{0, 2, 0, 0}'] * (64 - len(rows))
             P('  {' + ', '.join(rows) + '},')
         P('};')
+        P('enum { citw_%s_NBP = %d };' % (V, len(self.bpvec)))
+        P('static __device__ const CitwBpVec citw_%s_bpvec[%d] = {%s};' % (V, len(self.bpvec), ', '.join('{%d, %d}' % ((a >> 3) - lw, n) for a, n in self.bpvec)))
         P('static __device__ const CitwLookup citw_%s_lookup[%d][2][64] = {' % (V, self.nrounds))
         for R in self.rounds:
             rows2 = ['{%d, %d, %d, %d, %d, %d, %d, %d, %d}' % ((e['xr'] >> 3) - lw, e['nr'], (e['xc'] >> 3) - lw, (e['z'] >> 3) - lw, e['sx'], e['sy'],
