@@ -46,17 +46,44 @@ void serl_launch_dyn_ice(const RolloutArgs &a, const double *cmds, double *state
   void serl_launch_dyn_wave_##v(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
 SERL_DECL_WAVE(nominal) SERL_DECL_WAVE(ice) SERL_DECL_WAVE(cg_timed) SERL_DECL_WAVE(gust) SERL_DECL_WAVE(test)
 
-// two wavefronts per episode (rollout_team.inc): the latency-bound regime, fewer episodes than CUs
-void serl_launch_rollout_team_nominal(const RolloutArgs &a, int grid, hipStream_t stream);
-void serl_launch_dyn_team_nominal(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
-static bool serl_has_team_kernel(int code) { return code == SERL_DYN_NOMINAL; }
-// SERL_TEAM=0 never, =1 always (when the variant has it); default: when every episode can have a CU of its own
+// two wavefronts per episode (rollout_team.inc): the latency-bound regime
+#define SERL_DECL_TEAM(v)                                                                                     \
+  void serl_launch_rollout_team_##v(const RolloutArgs &a, int grid, hipStream_t stream);                          \
+  void serl_launch_dyn_team_##v(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
+SERL_DECL_TEAM(nominal) SERL_DECL_TEAM(ice) SERL_DECL_TEAM(cg_timed) SERL_DECL_TEAM(gust) SERL_DECL_TEAM(test)
+
+// One episode per workgroup and one workgroup per CU (the LDS copy of the tables): a team finishes an env step in
+// ~0.76 of the time a lone wavefront needs, but only 256 teams run at once where 1 024 lone wavefronts would.
+// Measured crossover ~330 episodes (profiles/): teams below, lone wavefronts above.  SERL_TEAM=0 / 1 overrides.
+#define SERL_TEAM_MAX_EPISODES 320
 static bool serl_use_team(int code, int episodes)
 {
-  if (!serl_has_team_kernel(code)) return false;
+  (void)code;
   const char *env = getenv("SERL_TEAM");
   if (env) return atoi(env) != 0;
-  return false;
+  return episodes <= SERL_TEAM_MAX_EPISODES;
+}
+
+static void serl_launch_rollout_team(int code, const RolloutArgs &a, int grid, hipStream_t stream)
+{
+  switch (code) {
+    case SERL_DYN_NOMINAL: serl_launch_rollout_team_nominal(a, grid, stream); break;
+    case SERL_DYN_ICE: serl_launch_rollout_team_ice(a, grid, stream); break;
+    case SERL_DYN_CG_TIMED: serl_launch_rollout_team_cg_timed(a, grid, stream); break;
+    case SERL_DYN_GUST: serl_launch_rollout_team_gust(a, grid, stream); break;
+    default: serl_launch_rollout_team_test(a, grid, stream); break;
+  }
+}
+
+static void serl_launch_dyn_team(int code, const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream)
+{
+  switch (code) {
+    case SERL_DYN_NOMINAL: serl_launch_dyn_team_nominal(a, cmds, states, T, grid, stream); break;
+    case SERL_DYN_ICE: serl_launch_dyn_team_ice(a, cmds, states, T, grid, stream); break;
+    case SERL_DYN_CG_TIMED: serl_launch_dyn_team_cg_timed(a, cmds, states, T, grid, stream); break;
+    case SERL_DYN_GUST: serl_launch_dyn_team_gust(a, cmds, states, T, grid, stream); break;
+    default: serl_launch_dyn_team_test(a, cmds, states, T, grid, stream); break;
+  }
 }
 
 // The wave-cooperative kernels (one wavefront per episode, rollout_wave.inc) exist for every code variant; the
@@ -199,7 +226,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     a.lanes = 1;
     a.block = 128;
     HIP_TRY(hipEventRecord(c->ev0, stream));
-    serl_launch_rollout_team_nominal(a, d->n_episodes, stream);
+    serl_launch_rollout_team(s.code, a, d->n_episodes, stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = true;
@@ -259,7 +286,7 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
     a.lanes = 1;
     a.block = 128;
     HIP_TRY(hipEventRecord(c->ev0, stream));
-    serl_launch_dyn_team_nominal(a, cmds, states, T, n_episodes, stream);
+    serl_launch_dyn_team(s.code, a, cmds, states, T, n_episodes, stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = true;

@@ -52,3 +52,11 @@ def test_generated_sources_are_current(variant):
     text = codegen.Gen(variant).emit()
     have = open(os.path.join(ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_wave.inc' % variant)).read()
     assert text == have, 'serl_amd/csrc/gen/citation_%s_wave.inc is stale: run python tools/dag/codegen.py' % variant
+
+
+@pytest.mark.parametrize('variant', ['nominal', 'gust'])
+def test_generated_team_sources_are_current(variant):
+    import codegen_team
+    text = codegen_team.TeamGen(variant).emit_team()
+    have = open(os.path.join(ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_team.inc' % variant)).read()
+    assert text == have, 'serl_amd/csrc/gen/citation_%s_team.inc is stale: run python tools/dag/codegen_team.py' % variant

@@ -24,11 +24,14 @@ import build_dag, codegen
 from codegen import LOOKUPS, hexf
 
 LEAF = ('cf', 'ci', 'in', 'in_i', 'true', 'false')
+POST_ROUND2_COST = 300      # instruction estimate of the later look-up rounds wave 0 runs after the first barrier
 LOOKUP_PHASES = int(os.environ.get('CITW_TEAM_LOOKUP_COST', 1400))   # instruction estimate of search + 2-D + 1-D passes
 LIBM = ('sc_sin', 'sc_cos', 'sin', 'cos', 'tan', 'exp', 'log10', 'log', 'atan', 'pow')
 
 
 class TeamGen(codegen.Gen):
+    split_post = True
+
     def closure(self, sinks, within):
         out, st = set(), list(sinks)
         while st:
@@ -99,6 +102,47 @@ class TeamGen(codegen.Gen):
         self.own0_xdot = [i for i in range(19) if i not in self.own1_xdot]
         self.own1_dw = [k for k, n in sorted(self.dw_out.items()) if (owner.get(n) == 1 or g.nodes[n][0] in LEAF) and g.nodes[n] != ('in', 'DW', k)]
         self.own0_dw = [k for k, n in sorted(self.dw_out.items()) if k not in self.own1_dw and g.nodes[n] != ('in', 'DW', k)]
+
+        # ---- the glue AFTER the look-ups: derivative cones are shared out the same way.  Cones that need a later
+        # look-up round stay on wave 0 (it runs those rounds); what a wave needs from the other's pre-barrier values
+        # is exchanged through g_x before the first barrier.
+        post = set(n for n in self.order if self.rnd[n] >= 1 and g.nodes[n][0] not in LEAF + LOOKUPS)
+        psinks = [n for n in dict.fromkeys(list(self.xdot) + list(self.dw_out.values())) if n in post]
+        pcones = {n: self.closure([n], post) for n in psinks}
+        phave = [set(), set()]
+        pload = [POST_ROUND2_COST if self.nrounds > 1 else 0, 0]
+        self.powner = {}
+        for n in sorted(psinks, key=lambda n: -sum(cost(m) for m in pcones[n])):
+            forced0 = self.rnd[n] >= 2 or not self.split_post
+            res = [pload[b] + sum(cost(m) for m in pcones[n] if m not in phave[b]) for b in (0, 1)]
+            b = 0 if (forced0 or res[0] <= res[1]) else 1
+            phave[b].update(pcones[n]); pload[b] = res[b]; self.powner[n] = b
+        self.post, self.phave, self.post_load = post, phave, pload
+        pre_ok = lambda c: c not in post and g.nodes[c][0] not in LEAF + LOOKUPS
+        need = [set(), set()]
+        for b in (0, 1):
+            for m in phave[b]:
+                for c in build_dag.children(g, m):
+                    if pre_ok(c):
+                        need[b].add(c)
+        for R in self.rounds[1:]:                     # inputs of later look-up rounds are computed by wave 0
+            for c in R['ins']:
+                if pre_ok(c):
+                    need[0].add(c)
+        exp10 = [n for n in self.order if n in need[0] and n not in A0x]       # wave 1 -> wave 0
+        exp01 = [n for n in self.order if n in need[1] and n not in A1]        # wave 0 -> wave 1
+        assert all(n in A1 for n in exp10) and all(n in A0x for n in exp01)
+        self.exports, self.exports01 = exp10, exp01
+        self.xslot = {n: k for k, n in enumerate(exp10)}
+        self.xslot01 = {n: 128 + k for k, n in enumerate(exp01)}
+        assert len(exp10) <= 128 and len(exp01) <= 128
+        for i, n in enumerate(self.xdot):
+            if n in post:
+                if self.powner[n] == 1:
+                    self.own1_xdot.append(i); self.own0_xdot.remove(i)
+        for k, n in sorted(self.dw_out.items()):
+            if n in post and self.powner[n] == 1:
+                self.own1_dw.append(k); self.own0_dw.remove(k)
 
     # ---- libm phase for an explicit set of nodes (level-1 libm nodes among `needed`)
     def libm_plan(self, needed):
@@ -214,14 +258,32 @@ class TeamGen(codegen.Gen):
             B('  const int lane = threadIdx.x & 63;')
             B('  %s;' % ('CITW_U0()' if which == 1 else 'CITW_T0()'))
             if which == 1:
+                # Derivative-block bank inputs: read all of them before B1 (either wave rewrites its banks after B1)
+                mine, st, seen = set(), [n for n in self.powner if self.powner[n] == 1] + list(self.A1), set()
+                while st:
+                    m = st.pop()
+                    if m in seen:
+                        continue
+                    seen.add(m)
+                    if m in self.xslot01:
+                        continue
+                    if g.nodes[m][0] == 'in' and g.nodes[m][1] == 'DW':
+                        mine.add(m)
+                    st.extend(build_dag.children(g, m))
+                self.in_override = {}
+                for m in sorted(mine):
+                    B('  const double dw%d = g_dw[0][%d];' % (g.nodes[m][2], g.nodes[m][2]))
+                    self.in_override[m] = 'dw%d' % g.nodes[m][2]
                 libm_phase(self.A1)
                 B('  /* ---- look-up independent glue */')
                 for n in self.exports:
                     emit_node(n, self.A1)
-                for i in self.own1_xdot:
+                pre1_xdot = [i for i in self.own1_xdot if self.xdot[i] not in self.post]
+                for i in pre1_xdot:
                     emit_node(self.xdot[i], self.A1)
                 for k in self.own1_dw:
-                    emit_node(self.dw_out[k], self.A1)
+                    if self.dw_out[k] not in self.post:
+                        emit_node(self.dw_out[k], self.A1)
                 emit_node(self.stop)
                 B('  STOP = %s;' % self.ref(self.stop))
                 B('  if (lane == 0) {')
@@ -231,12 +293,33 @@ class TeamGen(codegen.Gen):
                     else:
                         assert g.ty[n] == 'f'
                         B('    g_x[%d] = %s;' % (self.xslot[n], self.ref(n)))
-                for i in self.own1_xdot:
+                for i in pre1_xdot:
                     B('    g_f[0][stage][%d] = %s;' % (i, self.ref(self.xdot[i])))
                 B('  }')
                 B('  CITW_U(10);')
                 B('  __syncthreads();   /* B1: exports visible to wave 0; wave 0 has read the Derivative-block banks */')
                 B('  CITW_U(11);')
+                mine_post = [n for n in self.powner if self.powner[n] == 1]
+                if mine_post:
+                    B('  /* ---- share of wave 1 in the glue behind the look-ups */')
+                    for n in self.exports01:
+                        if g.ty[n] == 'b':
+                            B('  const bool b%d = g_x[%d] != 0.0;' % (n, self.xslot01[n]))
+                        else:
+                            B('  const double v%d = g_x[%d];' % (n, self.xslot01[n]))
+                        emitted.add(n)
+                    lk = [m for m in self.order if g.nodes[m][0] in LOOKUPS and any(u in self.phave[1] for u in self.users[m])]
+                    for m in lk:
+                        assert self.outslot[m][0] == 0
+                        emitted.add(m)
+                        B(self.stmt(m))
+                    for n in mine_post:
+                        emit_node(n)
+                    B('  if (lane == 0) {')
+                    for i, n in enumerate(self.xdot):
+                        if n in self.powner and self.powner[n] == 1:
+                            B('    g_f[0][stage][%d] = %s;' % (i, self.ref(n)))
+                    B('  }')
                 if self.own1_dw:
                     B('  if (major && lane == 0) {')
                     for k in self.own1_dw:
@@ -244,6 +327,7 @@ class TeamGen(codegen.Gen):
                     B('  }')
                 B('  __syncthreads();   /* B2 */')
                 B('  CITW_U(12);')
+                self.in_override = {}
             else:
                 # Derivative-block bank inputs this wave reads: load them before B1 (wave 1 rewrites the banks after B1)
                 mine = set()
@@ -296,6 +380,14 @@ class TeamGen(codegen.Gen):
                         for n in self.sinks0:
                             if g.ty[n] == 'f' and g.nodes[n][0] not in LEAF:
                                 B('  asm volatile("" :: "v"(%s));' % self.ref(n))
+                        if self.exports01:
+                            B('  if (lane == 0) {')
+                            for n in self.exports01:
+                                if g.ty[n] == 'b':
+                                    B('    g_x[%d] = %s ? 1.0 : 0.0;' % (self.xslot01[n], self.ref(n)))
+                                else:
+                                    B('    g_x[%d] = %s;' % (self.xslot01[n], self.ref(n)))
+                            B('  }')
                         B('  CITW_T(0);')
                         B('  __syncthreads();   /* B1: the exports of wave 1 are in g_x */')
                         B('  CITW_T(1);')
@@ -305,9 +397,11 @@ class TeamGen(codegen.Gen):
                             else:
                                 B('  const double v%d = g_x[%d];' % (n, self.xslot[n]))
                             emitted.add(n)
+                    mine0 = self.phave[0] | set(n for RR in self.rounds[1:] for n in RR['ins'])
                     for e in R['L2'] + R['L1']:
                         emitted.add(e['node'])
-                        B(self.stmt(e['node']))
+                        if r > 0 or any(u in mine0 for u in self.users[e['node']]):
+                            B(self.stmt(e['node']))
                 B('  /* ---- derivatives */')
                 for i in self.own0_xdot:
                     emit_node(self.xdot[i])
