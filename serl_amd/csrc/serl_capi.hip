@@ -53,15 +53,16 @@ SERL_DECL_WAVE(nominal) SERL_DECL_WAVE(ice) SERL_DECL_WAVE(cg_timed) SERL_DECL_W
 SERL_DECL_TEAM(nominal) SERL_DECL_TEAM(ice) SERL_DECL_TEAM(cg_timed) SERL_DECL_TEAM(gust) SERL_DECL_TEAM(test)
 
 // One episode per workgroup and one workgroup per CU (the LDS copy of the tables): a team finishes an env step in
-// ~0.76 of the time a lone wavefront needs, but only 256 teams run at once where 1 024 lone wavefronts would.
-// Measured crossover ~330 episodes (profiles/): teams below, lone wavefronts above.  SERL_TEAM=0 / 1 overrides.
-#define SERL_TEAM_MAX_EPISODES 320
+// ~0.75 of the time a lone wavefront needs (42.7 vs 57.5 us), but only one team fits a CU where four lone wavefronts
+// would: teams while every episode gets a CU of its own (measured: 320 episodes as teams 88 us, 400 alone 59 us),
+// lone wavefronts beyond.  SERL_TEAM=0 / 1 overrides.
+static int g_num_cus = 256;       // multiProcessorCount of the context's device (set by serl_ctx_create)
 static bool serl_use_team(int code, int episodes)
 {
   (void)code;
   const char *env = getenv("SERL_TEAM");
   if (env) return atoi(env) != 0;
-  return episodes <= SERL_TEAM_MAX_EPISODES;
+  return episodes <= g_num_cus;
 }
 
 static void serl_launch_rollout_team(int code, const RolloutArgs &a, int grid, hipStream_t stream)
@@ -149,6 +150,10 @@ int serl_ctx_create(int device, serl_ctx **out)
   serl_ctx *c = new (std::nothrow) serl_ctx();
   if (!c) return fail(SERL_E_NOMEM, "serl_ctx_create: out of memory");
   c->device = device;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) g_num_cus = prop.multiProcessorCount;
+  }
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   *out = c;
