@@ -94,7 +94,7 @@ def main():
 
     def one_step():
         """one population evaluation on this rank + the fitness all-gather"""
-        out = eng.rollout(w, spec, moe, ref, t_max=80.0, traces=True, lanes_per_wave=a.lanes, sync=False)
+        out = eng.rollout(w, spec, moe, ref, t_max=80.0, traces='actions', lanes_per_wave=a.lanes, sync=False)
         ls = out['length_steps']
         sm = metrics.calc_smoothness(out['actions'], ls)                          # a11, on device
         fit = out['fitness']
@@ -136,6 +136,15 @@ def main():
     k_ms = float(np.mean(kernel_ms))
     ach_hbm = steps_local * B_ALG / (k_ms * 1e-3)
     ach_f64 = steps_local * F_ALG / (k_ms * 1e-3)
+    # HBM traffic of one launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    # collected and corrected as MI355X_MICROARCH.md prescribes); only quoted for the configuration it was measured on
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_c_pmc_traffic.json')))
+        if pop == 50 and ne == 3 and a.lanes == 0:
+            traffic = pm['traffic_bytes_per_launch']
+    except Exception:
+        pass
     res = {
         'metric': 'env-steps/sec (whole node), pop-rollout eval, pop=%d nominal per GPU' % pop,
         'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -148,9 +157,10 @@ def main():
                    'lanes_per_wave': a.lanes, 'parallelism': 'member-sharded dp%d' % world},
         'kernel_ms': k_ms,
         'roofline': {'bound': 'hbm', 'achieved': ach_hbm / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                     'frac': ach_hbm / HBM_PEAK, 'traffic': None,
-                     'note': 'path is latency/occupancy-bound f64 VALU work, not HBM-bound (DESIGN.md): '
-                             'algorithmic traffic is 48 B per env-step'},
+                     'frac': ach_hbm / HBM_PEAK, 'traffic': traffic,
+                     'note': 'path is instruction-issue bound on one / two wavefronts per episode, not HBM-bound (DESIGN.md): '
+                             'algorithmic traffic is 48 B per env-step; achieved = steps x 48 B / kernel time; traffic = bytes '
+                             'per launch from profiles/r01_c_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE)'},
         'roofline_fp64': {'bound': 'valu-f64', 'achieved': ach_f64 / 1e12, 'peak': FP64_PEAK / 1e12, 'unit': 'TFLOP/s',
                           'frac': ach_f64 / FP64_PEAK},
         't_step_us': k_ms * 1e3 / T,

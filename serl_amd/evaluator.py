@@ -121,11 +121,13 @@ class RolloutEngine:
             an = torch.as_tensor(action_noise, dtype=torch.float64).to(dev).contiguous()
             assert an.shape == (E, T, 3)
             d.action_noise = an.data_ptr(); keep.append(an)
-        if traces:
+        if traces:      # True: actions + states + rewards; 'actions': only the action trace (what calc_smoothness needs)
             out['actions'] = torch.zeros(E, T, 3, dtype=torch.float64, device=dev)
-            out['states'] = torch.zeros(E, T, 12, dtype=torch.float64, device=dev)
-            out['rewards'] = torch.zeros(E, T, dtype=torch.float64, device=dev)
-            d.actions, d.states, d.rewards = out['actions'].data_ptr(), out['states'].data_ptr(), out['rewards'].data_ptr()
+            d.actions = out['actions'].data_ptr()
+            if traces != 'actions':
+                out['states'] = torch.zeros(E, T, 12, dtype=torch.float64, device=dev)
+                out['rewards'] = torch.zeros(E, T, dtype=torch.float64, device=dev)
+                d.states, d.rewards = out['states'].data_ptr(), out['rewards'].data_ptr()
         if transitions:
             out['transitions'] = torch.zeros(E, T, 20, dtype=torch.float32, device=dev)
             d.transitions = out['transitions'].data_ptr()
@@ -207,6 +209,7 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
     assert len(modes) == E
     resolved = [builds.resolve_mode(m) for m in modes]
     need_actions = traces or smooth_fitness or need_smoothness
+    want = True if traces else ('actions' if need_actions else False)
     tick0 = None if tick0 is None else np.asarray(tick0, dtype=np.int32).reshape(E)
     err0 = None if err0 is None else np.asarray(err0, dtype=np.float64).reshape(E, 3)
     # one kernel launch per dynamics build (be/jr/sa/se share the nominal build as per-episode fault rows; cg, ice,
@@ -223,7 +226,7 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
         o = engine.rollout(w, spec, moe[idx], refs if (whole or refs.dim() == 2) else refs[torch.as_tensor(idx)], build=b,
                            faults=faults, err0=None if err0 is None else err0[idx],
                            tick0=None if tick0 is None else tick0[idx], t_max=t_max,
-                           traces=need_actions, transitions=transitions, lanes_per_wave=lanes_per_wave)
+                           traces=want, transitions=transitions, lanes_per_wave=lanes_per_wave)
         kernel_ms += engine.last_kernel_ms
         if whole:
             out = o
