@@ -260,6 +260,47 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
                      episode_member=moe)
 
 
+def validate_pop(actors, refs, *, mode='nominal', t_max=80, spec: Optional[NetSpec] = None,
+                 engine: Optional[RolloutEngine] = None):
+    """The `-eval_pop` loop of the reference (base/evaluate.py:236-256 over validate_agent :123-150 over evaluate
+    :59-120) in one launch: every actor flies every reference table of `refs` (f64 [num_trails+1, T, 3] rad).
+
+    As in the reference's evaluate(), the error history pairs ref(t_k) with the controlled state BEFORE step k
+    (the state env.reset() / the previous step left), the action history is env.last_u before step k (zeros first),
+    nMAE = calc_nMAE(errors) and smoothness = calc_smoothness(actions).  Returns dict(nmae [R, pop], smoothness
+    [R, pop], nmae_mean / nmae_sd / sm_mean / sm_sd [pop], champion = first index of the smallest mean nMAE)."""
+    engine = engine or default_engine()
+    if spec is None:
+        spec = spec_of(actors[0])
+    w = _as_weights(actors, spec)
+    pop = w.shape[0]
+    refs = torch.as_tensor(refs, dtype=torch.float64)
+    if refs.dim() == 2:
+        refs = refs[None]
+    R = refs.shape[0]
+    E = pop * R
+    moe = np.repeat(np.arange(pop, dtype=np.int32), R)
+    build, row = builds.resolve_mode(mode)
+    out = engine.rollout(w, spec, moe, refs.repeat(pop, 1, 1), build=build,
+                         faults=None if row == builds.NOMINAL_ROW else [row] * E, t_max=t_max, traces=True)
+    dev = out['states'].device
+    n = out['length_steps'].to(torch.int64).abs()
+    data, _ = builds.load(build)
+    x0 = torch.as_tensor(np.asarray(data['x0'][:12], dtype=np.float64), device=dev)
+    T = refs.shape[1]
+    xb = torch.cat([x0.expand(E, 1, 12), out['states'][:, :T - 1]], 1)            # env.x before step k
+    ub = torch.cat([torch.zeros(E, 1, 3, dtype=torch.float64, device=dev), out['actions'][:, :T - 1]], 1)
+    ref_e = refs.to(dev).repeat(pop, 1, 1)
+    err = ref_e - xb[:, :, [7, 6, 5]]
+    nm = np.array([metrics.calc_nMAE(err[e, :int(n[e])]) for e in range(E)])
+    sm = metrics.calc_smoothness(ub, n).cpu().numpy()
+    nm, sm = nm.reshape(pop, R).T, sm.reshape(pop, R).T
+    res = dict(nmae=nm, smoothness=sm, nmae_mean=nm.mean(0), nmae_sd=nm.std(0), sm_mean=sm.mean(0), sm_sd=sm.std(0),
+               length_steps=out['length_steps'].cpu().numpy().reshape(pop, R).T, kernel_ms=engine.last_kernel_ms)
+    res['champion'] = int(np.argmin(res['nmae_mean']))          # `if stats.nmae < nmae_min` keeps the first minimum
+    return res
+
+
 def make_evaluate(args, *, mode='nominal', t_max=20, ref_fn=None, engine=None, replay_buffer=None, counters=None):
     """-> evaluate(agent, is_action_noise, store_transition) -> Episode, the signature of
     Agent.evaluate (base/core/agent.py:63-66).  One episode per call (the batched path is evaluate_pop).
