@@ -103,3 +103,30 @@ def synthetic_reference_tables(n_episodes, num_evals, t_max=80, seed=7):
         a_ph = rng.choice(np.linspace(-10, 10, 6), size=6)
         out[e] = tabulate(SmoothedStepSequence(tt, a_th, t_max // 10), SmoothedStepSequence(tt, a_ph, t_max // 10), t_max)
     return out
+
+
+def tabulate_batch_device(times, amps_theta, amps_phi, smooth_width, t_max, device=None, theta_trim_deg=0.22, dt=0.01):
+    """Device-side tabulation of E smoothed-step references at once: the same formula as
+    SmoothedStepSequence / tabulate, evaluated with torch on `device`, so that a population's reference tables never
+    exist on the host.  times / amps_*: [E, K] (degrees); -> f64 [E, n_steps, 3] radians.
+    The sample times t_k are the env's sequentially accumulated ones (computed once on the host: a parallel scan
+    would round differently)."""
+    import torch
+    n = n_steps_for(t_max, dt)
+    t = torch.as_tensor(env_times(n, dt), dtype=torch.float64, device=device)[None, :]            # [1, n]
+    times = torch.as_tensor(np.asarray(times), dtype=torch.float64, device=device)
+    out = []
+    for amps in (amps_theta, amps_phi):
+        amps = torch.as_tensor(np.asarray(amps), dtype=torch.float64, device=device)
+        v = torch.zeros(times.shape[0], n, dtype=torch.float64, device=device)
+        prev = torch.zeros(times.shape[0], 1, dtype=torch.float64, device=device)
+        for k in range(times.shape[1]):
+            ti, a = times[:, k:k + 1], amps[:, k:k + 1]
+            s = torch.clamp((t - ti) / float(smooth_width), max=1.0)
+            v = torch.where(t >= ti, prev + (a - prev) * (1 - torch.cos(np.pi * s)) / 2, v)
+            prev = a
+        out.append(v)
+    inside = ((t >= 0.0) & (t <= t_max)).to(torch.float64)
+    th = out[0] + theta_trim_deg * inside
+    ref = torch.stack([th, out[1], torch.zeros_like(th)], dim=2)
+    return ref * (np.pi / 180.0)

@@ -96,3 +96,17 @@ def test_reference_tables_and_mode_names(golden):
     assert builds.resolve_mode('be')[1][0] == 0.3                      # envs/be/citation.py:73  cmd[0] *= 0.3
     with pytest.raises(ValueError):
         builds.resolve_mode('no-such-mode')
+
+
+def test_batched_reference_tabulation_matches_the_host_tables():
+    from serl_amd import refsignals
+    rng = np.random.default_rng(5)
+    tt = np.tile(np.linspace(0.0, 80, 6), (4, 1))
+    a_th = rng.choice(np.linspace(-12, 12, 6), size=(4, 6)); a_th[:, 0] = 0.0
+    a_ph = rng.choice(np.linspace(-10, 10, 6), size=(4, 6))
+    got = refsignals.tabulate_batch_device(tt, a_th, a_ph, 8, 80).numpy()
+    for e in range(4):
+        want = refsignals.tabulate(refsignals.SmoothedStepSequence(tt[e], a_th[e], 8),
+                                   refsignals.SmoothedStepSequence(tt[e], a_ph[e], 8), 80)
+        np.testing.assert_allclose(got[e], want, rtol=0, atol=1e-15)
+    assert got.shape == (4, 8001, 3) and got[0, -1, 0] != got[0, -2, 0]     # the trim drops out at the terminal sample
