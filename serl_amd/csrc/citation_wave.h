@@ -42,6 +42,7 @@ __shared__ double g_f[CITW_MAX_WAVES][6][20];     // ODE5 stage derivatives
 __shared__ double g_xs[CITW_MAX_WAVES][20];       // continuous states X[19] of the current stage (lane i writes state i)
 __shared__ double g_cmd[CITW_MAX_WAVES][12];      // command vector of the current env step
 __shared__ double g_act[CITW_MAX_WAVES][16][3];   // action trace of the last <= 16 env steps (flushed as one coalesced store)
+__shared__ double g_inv[CITW_MAX_WAVES][128];     // per-step invariants of the model (citw_<v>_step_invariants)
 __shared__ double g_x[256];                       // team kernels: values wave 1 computes for wave 0 (rollout_team.inc)
 
 #define CITW_MAX_CONSTS 192

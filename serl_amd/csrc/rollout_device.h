@@ -11,6 +11,10 @@
 // Included once per dynamics code variant with DYN_STEP defined.
 #pragma once
 #include "../../include/serl_amd.h"
+#ifndef CITW_T            // phase-profile marks (citation_wave.h, -DCITW_PROFILE builds); no-ops elsewhere
+#define CITW_T(k) ((void)0)
+#define CITW_T0() ((void)0)
+#endif
 
 struct RolloutArgs {
   serl_rollout_desc d;
@@ -263,6 +267,7 @@ static __device__ void serl_actor_forward_small(const serl_rollout_desc &dd, con
       nbi = (outl + (size_t)3 * H)[io];
     }
   };
+  CITW_T0();
   issue(0);
   float h;
   {
@@ -274,6 +279,7 @@ static __device__ void serl_actor_forward_small(const serl_rollout_desc &dd, con
     for (int j = 0; j < 7; ++j) acc = acc + w0[j] * obs[j];
     h = serl_act(acc, act);
   }
+  CITW_T(22);
   for (int l = 0; l <= L; ++l) {
     float row[H];
 #pragma unroll
@@ -283,6 +289,7 @@ static __device__ void serl_actor_forward_small(const serl_rollout_desc &dd, con
     if (l < L) issue(l + 1);
 #pragma unroll
     for (int j = 0; j < H; ++j) acc = acc + row[j] * serl_bcast(h, j);
+    CITW_T(23);
     if (l < L) {
       float mean = 0.0f;
 #pragma unroll
@@ -299,6 +306,7 @@ static __device__ void serl_actor_forward_small(const serl_rollout_desc &dd, con
 #pragma unroll
       for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, i);
     }
+    CITW_T(24);
   }
 }
 

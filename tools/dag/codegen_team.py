@@ -56,7 +56,7 @@ class TeamGen(codegen.Gen):
             for c in build_dag.children(g, n):
                 users[c].append(n)
         self.users = users
-        glue = lambda n: g.nodes[n][0] not in LEAF + LOOKUPS
+        glue = lambda n: g.nodes[n][0] not in LEAF + LOOKUPS and not self.inv[n]      # per-step invariants come from LDS
         S0 = set(n for n in self.order if self.rnd[n] == 0 and glue(n))
         A0 = self.closure([n for n in self.rounds[0]['ins'] if n in S0], S0)
         roots = list(dict.fromkeys(list(self.xdot) + list(self.dw_out.values())))
@@ -304,6 +304,12 @@ class TeamGen(codegen.Gen):
             for m in sorted(mine):
                 B('  const double dw%d = g_dw[0][%d];' % (g.nodes[m][2], g.nodes[m][2]))
                 self.in_override[m] = 'dw%d' % g.nodes[m][2]
+            if self.inv_frontier:
+                B('  /* ---- per-step invariants (computed by every wave of the team into its own rows) */')
+                done_rounds.add(len(self.rounds))
+                for n in self.inv_frontier:
+                    B(self.inv_load(n))
+                    emitted.add(n)
             libm_phase(self.have[b])
             B('  %s;' % TM(4))
             if b == 0:
@@ -375,6 +381,7 @@ class TeamGen(codegen.Gen):
             text = '\n'.join(body)
             # shared blackboards live in row 0; each wave has its own libm / look-up input rows
             text = text.replace('g_in[wv]', 'g_in[%d]' % b).replace('g_m[wv]', 'g_m[%d]' % b)
+            text = text.replace('g_inv[wv]', 'g_inv[%d]' % b).replace('g_out%d[wv]' % len(self.rounds), 'g_out%d[%d]' % (len(self.rounds), b))
             text = text.replace('[wv]', '[0]').replace('(wv, ', '(%d, ' % b)
             return text
 
@@ -394,7 +401,7 @@ class TeamGen(codegen.Gen):
 def main():
     variants = [a for a in sys.argv[1:] if not a.startswith('--')] or ['nominal']
     for v in variants:
-        gen = TeamGen(v)
+        gen = TeamGen(v, hoist='--hoist-invariants' in sys.argv)
         text = gen.emit_team()
         path = os.path.join(build_dag.ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_team.inc' % v)
         open(path, 'w').write(text)
