@@ -310,6 +310,125 @@ static __device__ void serl_actor_forward_small(const serl_rollout_desc &dd, con
   }
 }
 
+// ---- LDS-resident actor (team kernels: one episode per workgroup, ~23 KB of LDS free beside the model tables) ----
+// The member's weights are staged once per episode into LDS in the order the lanes consume them, so a step reads no
+// weight from L2/HBM at all (a lone wavefront per SIMD has nothing to hide that latency with -- measured 3 k cycles per
+// env step, more when the wavefronts of a team queue up on the same rows):
+//   [0, 7H)            W0 transposed: W0t[j][i]               (lane i reads column j: consecutive addresses)
+//   [7H, 8H)           b0[i]
+//   per hidden layer l, base 8H + l (H*H + 3H):
+//     [0, H*H)         W as [H/4][H][4]: 16 B of row i, columns 4q..4q+3, at ((q*H + i) * 4)  (conflict-free ds_read_b128)
+//     [H*H, +3H)       bias[H], gamma[H], beta[H]
+//   output layer, base 8H + L (H*H + 3H):  [H/4][4][4] (rows 0..2, row 3 = padding), then bo[3]
+// Same operation order as serl_actor_forward_small (= the oracle's).
+#define SERL_LDS_ACTOR_H 32
+#define SERL_LDS_ACTOR_MAXL 3
+#define SERL_LDS_ACTOR_FLOATS (8 * 32 + 3 * (32 * 32 + 3 * 32) + 4 * 32 + 4)
+typedef const __attribute__((address_space(3))) float *serl_lptr;
+typedef const __attribute__((address_space(3))) serl_v4f *serl_lptr4;
+
+static __device__ __forceinline__ bool serl_lds_actor_ok(const serl_rollout_desc &dd)
+{
+  return dd.hidden == SERL_LDS_ACTOR_H && dd.num_layers <= SERL_LDS_ACTOR_MAXL && dd.state_dim == 7 && dd.action_dim == 3;
+}
+
+// whole workgroup; the caller synchronises afterwards
+static __device__ __forceinline__ void serl_stage_actor_lds(const serl_rollout_desc &dd, const float *w, float *lw)
+{
+  constexpr int H = SERL_LDS_ACTOR_H;
+  const int L = dd.num_layers;
+  constexpr int lstride = H * H + 3 * H;
+  for (int t = threadIdx.x; t < 7 * H; t += blockDim.x) { const int j = t / H, i = t - j * H; lw[t] = w[i * 7 + j]; }
+  for (int t = threadIdx.x; t < H; t += blockDim.x) lw[7 * H + t] = w[7 * H + t];
+  for (int l = 0; l < L; ++l) {
+    const float *src = w + 8 * H + (size_t)l * lstride;
+    float *dst = lw + 8 * H + l * lstride;
+    for (int t = threadIdx.x; t < H * H; t += blockDim.x) {
+      const int i = t / H, j = t - i * H;
+      dst[((j >> 2) * H + i) * 4 + (j & 3)] = src[t];
+    }
+    for (int t = threadIdx.x; t < 3 * H; t += blockDim.x) dst[H * H + t] = src[H * H + t];
+  }
+  const float *src = w + 8 * H + (size_t)L * lstride;
+  float *dst = lw + 8 * H + L * lstride;
+  for (int t = threadIdx.x; t < 4 * H; t += blockDim.x) {
+    const int q = t >> 4, i = (t >> 2) & 3, c = t & 3;
+    dst[t] = i < 3 ? src[i * H + 4 * q + c] : 0.0f;
+  }
+  for (int t = threadIdx.x; t < 3; t += blockDim.x) dst[4 * H + t] = src[3 * H + t];
+}
+
+static __device__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const float *lw_generic, const float obs[7],
+                                              float act_out[3])
+{
+  constexpr int H = SERL_LDS_ACTOR_H;
+  const int L = __builtin_amdgcn_readfirstlane(dd.num_layers), act = __builtin_amdgcn_readfirstlane(dd.activation);
+  serl_lptr lw = (serl_lptr)lw_generic;
+  const int lane = threadIdx.x & 63;
+  const int i0 = lane < H ? lane : H - 1, io = lane < 3 ? lane : 2;
+  constexpr int lstride = H * H + 3 * H;
+  serl_lptr hid = lw + 8 * H, outl = hid + L * lstride;
+  float nrow[H], nbi, ngm = 0.0f, nbt = 0.0f;
+  auto issue = [&](int l) {
+    if (l < L) {
+      serl_lptr base = hid + l * lstride;
+#pragma unroll
+      for (int q = 0; q < H / 4; ++q) {
+        const serl_v4f v = *(serl_lptr4)(base + (q * H + i0) * 4);
+        nrow[4 * q] = v.x; nrow[4 * q + 1] = v.y; nrow[4 * q + 2] = v.z; nrow[4 * q + 3] = v.w;
+      }
+      nbi = base[H * H + i0]; ngm = base[H * H + H + i0]; nbt = base[H * H + 2 * H + i0];
+    } else {
+#pragma unroll
+      for (int q = 0; q < H / 4; ++q) {
+        const serl_v4f v = *(serl_lptr4)(outl + (q * 4 + io) * 4);
+        nrow[4 * q] = v.x; nrow[4 * q + 1] = v.y; nrow[4 * q + 2] = v.z; nrow[4 * q + 3] = v.w;
+      }
+      nbi = outl[4 * H + io];
+    }
+  };
+  CITW_T0();
+  issue(0);
+  float h;
+  {
+    float acc = lw[7 * H + i0], w0[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) w0[j] = lw[j * H + i0];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc = acc + w0[j] * obs[j];
+    h = serl_act(acc, act);
+  }
+  CITW_T(22);
+  for (int l = 0; l <= L; ++l) {
+    float row[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) row[j] = nrow[j];
+    float acc = nbi;
+    const float gm = ngm, bt = nbt;
+    if (l < L) issue(l + 1);
+#pragma unroll
+    for (int j = 0; j < H; ++j) acc = acc + row[j] * serl_bcast(h, j);
+    CITW_T(23);
+    if (l < L) {
+      float mean = 0.0f;
+#pragma unroll
+      for (int j = 0; j < H; ++j) mean = mean + serl_bcast(acc, j);
+      mean = mean / (float)H;
+      const float d = acc - mean, dd2 = d * d;
+      float var = 0.0f;
+#pragma unroll
+      for (int j = 0; j < H; ++j) var = var + serl_bcast(dd2, j);
+      const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
+      h = serl_act(gm * d / den + bt, act);
+    } else {
+      const float t = det_tanhf(acc);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, i);
+    }
+    CITW_T(24);
+  }
+}
+
 static __device__ __forceinline__ void serl_actor_forward(const serl_rollout_desc &dd, const float *w, const float obs[7],
                                                           float act_out[3])
 {
