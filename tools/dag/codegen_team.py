@@ -3,7 +3,7 @@
 
 With one wavefront per SIMD every instruction -- VALU, SALU, LDS, waitcnt -- costs a 4-cycle issue slot, so one model
 evaluation (~4 500 instructions) is issue-bound on a single wavefront.  When there are fewer episodes than CUs, the
-other SIMDs of the CU take a share of the work: a team of K wavefronts (K = 3 by default) per episode.
+other SIMDs of the CU take a share of the work: a team of K wavefronts (K = 4 by default: one per SIMD of the CU) per episode.
 
   wave 0 (main)     the serial chain: libm calls + glue that the round-1 look-up inputs need -> index search, 2-D and
                     1-D interpolation passes -> [barrier B1] -> later look-up rounds, its share of the derivative cones
@@ -26,7 +26,7 @@ import build_dag, codegen
 from codegen import LOOKUPS, hexf
 
 LEAF = ('cf', 'ci', 'in', 'in_i', 'true', 'false')
-TEAM_WAVES = int(os.environ.get('CITW_TEAM_WAVES', 3))
+TEAM_WAVES = int(os.environ.get('CITW_TEAM_WAVES', 4))
 # instruction estimates used by the balancer (wave 0's fixed work: search + 2-D + 1-D passes; later look-up rounds)
 LOOKUP_PHASES = int(os.environ.get('CITW_TEAM_LOOKUP_COST', 1400))
 POST_ROUND2_COST = int(os.environ.get('CITW_TEAM_ROUND2_COST', 300))
