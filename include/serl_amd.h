@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SERL_ABI_VERSION 2
+#define SERL_ABI_VERSION 3
 
 enum serl_error {
   SERL_OK = 0,
@@ -84,8 +84,11 @@ typedef struct serl_rollout_desc {
   int64_t ref_stride;               /* doubles between consecutive episodes' tables (0 = shared) */
   const double *err0;               /* [n_episodes][3] tracking error carried into obs0
                                        (envs/phlabenv.py:401-428 never clears self.error) or NULL=0 */
-  const double *action_noise;       /* [n_episodes][max_steps][3] pre-drawn clipped Gaussian noise
+  const double *action_noise;       /* [rows][max_steps][3] pre-drawn clipped Gaussian noise
                                        (base/core/agent.py:90-93) or NULL */
+  const int32_t *noise_row;         /* [n_episodes] row of action_noise an episode adds to its actions, -1 = none
+                                       (a population evaluation and the RL actor's exploration episode share one
+                                       launch); NULL = row e for every episode */
   const int32_t *tick0;             /* [n_episodes] model clock (clockTick0) the episode starts with, or NULL = 0.
                                        The reference's initialize() @0xb4e0 resets the states but NOT the model
                                        clock (rtM clockTick0/1 and t keep counting across episodes of one process;

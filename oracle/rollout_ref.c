@@ -152,6 +152,11 @@ static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, in
   const serl_fault_row *f = d->faults ? &d->faults[e] : &nominal;
   const float *w = d->weights + (size_t)d->member_of_episode[e] * d->weight_stride;
   const double *ref = d->ref + (size_t)e * d->ref_stride;
+  const double *noise = NULL;                          /* this episode's row of pre-drawn action noise, if any */
+  if (d->action_noise) {
+    const int nr = d->noise_row ? d->noise_row[e] : e;
+    if (nr >= 0) noise = d->action_noise + (size_t)nr * d->max_steps * 3;
+  }
   double cmd[10], x[12], err[3] = {0, 0, 0}, obs[7];
   float obsf[7], a[3];
 
@@ -176,10 +181,10 @@ static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, in
     for (int i = 0; i < 7; ++i) obsf[i] = (float)obs[i];
     actor_forward(d, w, obsf, a, hbuf);
     double u[3];
-    if (d->action_noise) {
+    if (noise) {
       /* agent.py:90-93: f32 action + f64 noise -> f64, clipped; scale_action then runs in f64 */
       for (int i = 0; i < 3; ++i) {
-        double an = clipd((double)a[i] + d->action_noise[((size_t)e * d->max_steps + k) * 3 + i], -1.0, 1.0);
+        double an = clipd((double)a[i] + noise[(size_t)k * 3 + i], -1.0, 1.0);
         u[i] = low + 0.5 * (an + 1.0) * (high - low);
       }
     } else {

@@ -7,6 +7,7 @@ and the host-side mirror of the reference interface for this path:
   Episode                      base/core/utils.py:12-36            (episode.py)
   evaluate_pop / RolloutEngine  base/core/agent.py:63-138,229-256  (evaluator.py)
   make_evaluate                Agent.evaluate-compatible adaptor    (evaluator.py)
+  evaluate_generation / validate_actor  base/core/agent.py:188-209,229-269: a generation's rollouts in 3 launches (generation.py)
   validate_pop                 base/evaluate.py:59-150,236-256 (-eval_pop: nMAE / smoothness / champion)
   reference signals            `signals` call sites, envs/phlabenv.py:303-349 (refsignals.py)
   calc_smoothness / calc_nMAE  base/core/utils.py:39-58,82-120      (metrics.py)
@@ -19,7 +20,9 @@ library, or calling it without a GPU, raises -- there is no CPU fallback in the 
 from .actor import Actor, GeneticAgent, pack_actor, pack_population, NetSpec
 from .episode import Episode
 from .evaluator import RolloutEngine, evaluate_pop, validate_pop, make_evaluate, PopResult
+from .generation import evaluate_generation, validate_actor, GenerationResult
 from . import refsignals, metrics, ga, distributed, builds
 
 __all__ = ['Actor', 'GeneticAgent', 'pack_actor', 'pack_population', 'NetSpec', 'Episode', 'RolloutEngine',
-           'evaluate_pop', 'validate_pop', 'make_evaluate', 'PopResult', 'refsignals', 'metrics', 'ga', 'distributed', 'builds']
+           'evaluate_pop', 'validate_pop', 'make_evaluate', 'PopResult', 'evaluate_generation', 'validate_actor',
+           'GenerationResult', 'refsignals', 'metrics', 'ga', 'distributed', 'builds']

@@ -81,7 +81,7 @@ class RolloutEngine:
 
     # ------------------------------------------------------------------------------------------
     def rollout(self, weights, spec: NetSpec, member_of_episode, ref, *, build='h2000_v90', faults=None,
-                err0=None, tick0=None, action_noise=None, t_max=80.0, traces=False, transitions=False,
+                err0=None, tick0=None, action_noise=None, noise_row=None, t_max=80.0, traces=False, transitions=False,
                 lanes_per_wave=0, sync=True):
         """Low-level: run len(member_of_episode) episodes.  weights f32 [M, >=P] (device or host),
         ref f64 [E, T, 3] or [T, 3] radians.  Returns dict of device tensors."""
@@ -119,7 +119,12 @@ class RolloutEngine:
             d.tick0 = tk.data_ptr(); keep.append(tk)
         if action_noise is not None:
             an = torch.as_tensor(action_noise, dtype=torch.float64).to(dev).contiguous()
-            assert an.shape == (E, T, 3)
+            if noise_row is None:
+                assert an.shape == (E, T, 3)
+            else:           # an: [rows, T, 3]; noise_row[e] = row the episode adds to its actions, -1 = none
+                nr = torch.as_tensor(np.asarray(noise_row), dtype=torch.int32).to(dev).contiguous()
+                assert an.dim() == 3 and an.shape[1:] == (T, 3) and nr.numel() == E and int(nr.max()) < an.shape[0]
+                d.noise_row = nr.data_ptr(); keep.append(nr)
             d.action_noise = an.data_ptr(); keep.append(an)
         if traces:      # True: actions + states + rewards; 'actions': only the action trace (what calc_smoothness needs)
             out['actions'] = torch.zeros(E, T, 3, dtype=torch.float64, device=dev)
@@ -335,18 +340,8 @@ def make_evaluate(args, *, mode='nominal', t_max=20, ref_fn=None, engine=None, r
         states = out['states'][0, :n].cpu().numpy()
         state['err'] = ref[n - 1] - states[n - 1][[7, 6, 5]]
         if store_transition:
-            tr = out['transitions'][0, :n].cpu().numpy()
-            for row_ in tr:
-                t5 = (row_[0:7].astype(np.float64), row_[7:10], row_[10:17].astype(np.float64), float(row_[17]), float(row_[18]))
-                if replay_buffer is not None:
-                    replay_buffer.add(*t5)
-                if getattr(agent, 'buffer', None) is not None:
-                    agent.buffer.add(*t5)
-                if row_[19] and getattr(agent, 'critical_buffer', None) is not None:
-                    agent.critical_buffer.add(*t5)
-            counters['num_frames'] = counters.get('num_frames', 0) + n
-            counters['gen_frames'] = counters.get('gen_frames', 0) + n
-            counters['num_episodes'] = counters.get('num_episodes', 0) + 1
+            from .generation import store_transitions
+            store_transitions(out['transitions'][0, :n].cpu().numpy(), agent, replay_buffer, counters)
         smooth = float(metrics.calc_smoothness(actions[None], [n])[0])
         fitness = float(np.sum(rewards))
         if getattr(args, 'smooth_fitness', False):

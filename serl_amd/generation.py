@@ -1,0 +1,175 @@
+"""One ERL generation's rollouts in as few launches as their data dependencies allow.
+
+The reference's `Agent.train` (base/core/agent.py:211-315) runs, one episode at a time on one env:
+
+  1. pop x num_evals GA episodes, the last one of every member stored          agent.py:234-241
+  2. 5 validation episodes of the champion (argmax of the mean fitness)          agent.py:255-259, 188-209
+  3. SSNE.epoch                                                                  agent.py:264
+  4. one exploration episode of the RL actor (action noise, stored)              agent.py:269
+  5. TD3 updates, then 5 validation episodes of the updated RL actor             agent.py:271-275
+
+(1) and (4) depend on nothing computed in this generation, so they share ONE launch here
+(`evaluate_generation`: pop*num_evals + 1 episodes, the RL actor as an extra member row, its pre-drawn noise
+as the only row of the noise table); (2) needs the argmax of (1) and (5) needs the weights TD3 produced, so
+each is a launch of its own (`validate_actor`: all validation episodes of an actor together).  Three launches
+per generation instead of pop*num_evals + 11 sequential episodes.
+
+Replay-buffer semantics follow `Agent.evaluate` (agent.py:101-125): every stored transition goes to the shared
+buffer and to the acting agent's own buffer, cost-flagged ones also to its critical buffer; `num_frames`,
+`gen_frames` and `num_episodes` advance for stored episodes only.  Episodes start from a fresh env state
+(error carry-over and model clock: see `evaluate_pop`); the reference's per-step `np.random.randn` draws of the
+exploration noise are replaced by one up-front draw of T rows in the same order (the values coincide while the
+episode runs; the generator is left T - n rows further on when it stops early).
+"""
+from dataclasses import dataclass
+from typing import Optional, Sequence
+import numpy as np
+import torch
+
+from . import builds, metrics, refsignals
+from .actor import pack_population, spec_of
+from .episode import Episode
+from .evaluator import PopResult, RolloutEngine, default_engine
+
+
+@dataclass
+class GenerationResult:
+    pop: PopResult                    # the GA evaluate loop (agent.py:229-256)
+    rl_episode: Optional[Episode]     # the RL actor's exploration episode (agent.py:269), None without an RL actor
+    kernel_ms: float
+
+
+def store_transitions(rows, agent, replay_buffer=None, counters=None):
+    """rows: f32 [n, 20] = (obs7, a3, next_obs7, r, done, cost) of ONE stored episode -> the buffers of
+    agent.py:101-112 and the counters of agent.py:111-125."""
+    rows = np.asarray(rows)
+    buf = getattr(agent, 'buffer', None)
+    crit = getattr(agent, 'critical_buffer', None)
+    for r in rows:
+        t5 = (r[0:7].astype(np.float64), r[7:10], r[10:17].astype(np.float64), float(r[17]), float(r[18]))
+        if replay_buffer is not None:
+            replay_buffer.add(*t5)
+        if buf is not None:
+            buf.add(*t5)
+        if r[19] and crit is not None:
+            crit.add(*t5)
+    if counters is not None:
+        n = len(rows)
+        counters['num_frames'] = counters.get('num_frames', 0) + n
+        counters['gen_frames'] = counters.get('gen_frames', 0) + n
+        counters['num_episodes'] = counters.get('num_episodes', 0) + 1
+
+
+def _actor_of(agent):
+    return agent.actor if hasattr(agent, 'actor') else agent
+
+
+def _episode(out, e, ref_row, smooth, smooth_fitness):
+    n = abs(int(out['length_steps'][e]))
+    rewards = out['rewards'][e, :n].cpu().numpy()
+    fitness = float(np.sum(rewards))
+    if smooth_fitness:
+        fitness += float(smooth)
+    return Episode(fitness=fitness, smoothness=float(smooth), length=float(out['length_t'][e]),
+                   state_history=list(out['states'][e, :n].cpu().numpy()), ref_signals=np.asarray(ref_row[n - 1]),
+                   actions=out['actions'][e, :n].cpu().numpy(), reward_lst=list(rewards))
+
+
+def evaluate_generation(pop: Sequence, rl_agent=None, *, args, mode='nominal', t_max=20, refs=None, rl_noise=None,
+                        engine: Optional[RolloutEngine] = None, replay_buffer=None, counters=None,
+                        store: bool = True) -> GenerationResult:
+    """Steps (1) and (4) of a generation in one launch.
+
+    pop      : GeneticAgent / Actor sequence (one network shape); rl_agent: the RL learner's agent or None
+    args     : needs num_evals, smooth_fitness, noise_sd, noise_clip (base/parameters.py)
+    refs     : f64 [pop*num_evals (+1), T, 3] / [T, 3] radians (refsignals.tabulate); None = base reference
+    rl_noise : f64 [T, 3] clipped exploration noise; None = drawn here as agent.py:90-93 would
+    store    : append the transitions of every member's last evaluation and of the RL episode to the buffers"""
+    engine = engine or default_engine()
+    ne = int(args.num_evals)
+    actors = [_actor_of(a) for a in pop]
+    for a in actors:
+        a.eval()                                            # agent.py:83
+    spec = spec_of(actors[0])
+    n_pop = len(actors)
+    members = list(actors)
+    E = n_pop * ne
+    moe = np.repeat(np.arange(n_pop, dtype=np.int32), ne)
+    noise_row = None
+    if rl_agent is not None:
+        rl_actor = _actor_of(rl_agent)
+        rl_actor.eval()
+        assert spec_of(rl_actor) == spec, 'the RL actor must have the population\'s network shape'
+        members.append(rl_actor)
+        moe = np.append(moe, np.int32(n_pop))
+    Etot = len(moe)
+    if refs is None:
+        refs = refsignals.tabulate(*refsignals.base_reference(t_max), t_max)
+    refs = torch.as_tensor(refs, dtype=torch.float64)
+    T = refs.shape[-2]
+    if refs.dim() == 3:
+        assert refs.shape[0] == Etot, 'one reference table per episode (pop*num_evals%s)' % (' + 1' if rl_agent is not None else '')
+    noise = None
+    if rl_agent is not None:
+        if rl_noise is None:
+            rl_noise = np.clip(args.noise_sd * np.random.randn(T, 3), -args.noise_clip, args.noise_clip)
+        noise = np.asarray(rl_noise, dtype=np.float64).reshape(1, T, 3)
+        noise_row = np.full(Etot, -1, dtype=np.int32)
+        noise_row[-1] = 0
+    build, row = builds.resolve_mode(mode)
+    faults = None if row == builds.NOMINAL_ROW else [row] * Etot
+    out = engine.rollout(pack_population(members), spec, moe, refs, build=build, faults=faults, action_noise=noise,
+                         noise_row=noise_row, t_max=t_max, traces=True, transitions=store)
+    ls = out['length_steps'].cpu().numpy()
+    sm = metrics.calc_smoothness(out['actions'], np.abs(ls)).cpu().numpy()
+    ret = out['fitness'].cpu().numpy()
+    smooth_fitness = bool(getattr(args, 'smooth_fitness', False))
+    fit = ret + sm if smooth_fitness else ret.copy()
+    sh = lambda a: np.ascontiguousarray(np.asarray(a)[:E].reshape(n_pop, ne).T)
+    fitness = sh(fit)
+    pop_fitness = np.mean(fitness, axis=0)
+    res = PopResult(fitness=fitness, returns=sh(ret), smoothness=sh(sm), length_steps=sh(ls),
+                    length_t=sh(out['length_t'].cpu().numpy()), cost_steps=sh(out['cost_steps'].cpu().numpy()),
+                    pop_fitness=pop_fitness, champion=int(np.argmax(pop_fitness)), worst=int(np.argmin(pop_fitness)),
+                    kernel_ms=engine.last_kernel_ms, actions=out['actions'][:E], states=out['states'][:E],
+                    rewards=out['rewards'][:E], transitions=out.get('transitions'), episode_member=moe[:E])
+    if store:
+        tr = out['transitions']
+        for m in range(n_pop):                              # the reference's order: member by member
+            e = m * ne + ne - 1
+            store_transitions(tr[e, :abs(int(ls[e]))].cpu().numpy(), pop[m], replay_buffer, counters)
+    rl_ep = None
+    if rl_agent is not None:
+        e = Etot - 1
+        ref_row = refs[e] if refs.dim() == 3 else refs
+        rl_ep = _episode(out, e, ref_row.cpu().numpy(), sm[e], smooth_fitness)
+        if store:
+            store_transitions(out['transitions'][e, :abs(int(ls[e]))].cpu().numpy(), rl_agent, replay_buffer, counters)
+    return GenerationResult(pop=res, rl_episode=rl_ep, kernel_ms=engine.last_kernel_ms)
+
+
+def validate_actor(agent, *, tests=5, mode='nominal', t_max=20, refs=None, smooth_fitness=False,
+                   engine: Optional[RolloutEngine] = None):
+    """`Agent.validate_agent` (agent.py:188-209): `tests` episodes of one actor, nothing stored, all in one launch.
+    Returns the reference's tuple (test_score, test_sd, ep_len, ep_len_sd, last_episode, sm, sm_sd):
+    mean / std of sum(reward_lst), mean / std of the episode length, the last episode, median / std of smoothness."""
+    engine = engine or default_engine()
+    actor = _actor_of(agent)
+    actor.eval()
+    spec = spec_of(actor)
+    if refs is None:
+        refs = refsignals.tabulate(*refsignals.base_reference(t_max), t_max)
+    refs = torch.as_tensor(refs, dtype=torch.float64)
+    if refs.dim() == 3:
+        assert refs.shape[0] == tests
+    build, row = builds.resolve_mode(mode)
+    out = engine.rollout(pack_population([actor]), spec, np.zeros(tests, dtype=np.int32), refs, build=build,
+                         faults=None if row == builds.NOMINAL_ROW else [row] * tests, t_max=t_max, traces=True)
+    ls = np.abs(out['length_steps'].cpu().numpy())
+    sm = metrics.calc_smoothness(out['actions'], ls).cpu().numpy()
+    scores = np.array([float(np.sum(out['rewards'][e, :ls[e]].cpu().numpy())) for e in range(tests)])
+    lengths = out['length_t'].cpu().numpy()
+    e = tests - 1
+    last = _episode(out, e, (refs[e] if refs.dim() == 3 else refs).cpu().numpy(), sm[e], smooth_fitness)
+    return (float(np.mean(scores)), float(np.std(scores)), float(np.mean(lengths)), float(np.std(lengths)), last,
+            float(np.median(sm)), float(np.std(sm)))

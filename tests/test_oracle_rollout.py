@@ -180,3 +180,7 @@ def test_action_noise_path_and_table_exhaustion():
     np.testing.assert_allclose(c['fitness'], a['fitness'], rtol=1e-6)   # f64 vs f32 scaling of the same action
     with pytest.raises(RuntimeError):
         R.rollout(w, NET['serl50'], [0], ref[:100], t_max=20)
+    # per-episode noise rows (a population evaluation and the RL actor's exploration episode in one call)
+    m = R.rollout(w, NET['serl50'], [0, 0, 0], ref, t_max=20, action_noise=noise, noise_row=[-1, 0, -1])
+    assert m['fitness'][0] == a['fitness'][0] == m['fitness'][2] and m['fitness'][1] == b['fitness'][0]
+    assert (m['length_steps'] == [a['length_steps'][0], b['length_steps'][0], a['length_steps'][0]]).all()
