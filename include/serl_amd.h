@@ -89,6 +89,12 @@ typedef struct serl_rollout_desc {
   const int32_t *noise_row;         /* [n_episodes] row of action_noise an episode adds to its actions, -1 = none
                                        (a population evaluation and the RL actor's exploration episode share one
                                        launch); NULL = row e for every episode */
+  const double *sensor_noise;       /* [rows][max_steps + 1][7] additive sensor noise of the `noise` / `gust` wrappers
+                                       (envs/noise/citation.py:71-82, envs/gust/citation.py:72-86): bias + sd * randn,
+                                       pre-drawn in the wrapper's draw order, for the channels p q r | alpha | beta |
+                                       phi theta of what step() RETURNS (the plant state stays clean); entry 0 belongs
+                                       to the step reset() takes, entry k + 1 to env step k.  NULL = none */
+  const int32_t *sensor_row;        /* [n_episodes] row of sensor_noise, -1 = none; NULL = row e for every episode */
   const int32_t *tick0;             /* [n_episodes] model clock (clockTick0) the episode starts with, or NULL = 0.
                                        The reference's initialize() @0xb4e0 resets the states but NOT the model
                                        clock (rtM clockTick0/1 and t keep counting across episodes of one process;

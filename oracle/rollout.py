@@ -20,7 +20,7 @@ class RolloutDesc(ctypes.Structure):
                 ('weights', _F), ('weight_stride', ctypes.c_int64),
                 ('n_episodes', ctypes.c_int32), ('build_slot', ctypes.c_int32),
                 ('member_of_episode', _I), ('faults', _D), ('ref', _D), ('ref_stride', ctypes.c_int64),
-                ('err0', _D), ('action_noise', _D), ('noise_row', _I), ('tick0', _I), ('t_max', ctypes.c_double),
+                ('err0', _D), ('action_noise', _D), ('noise_row', _I), ('sensor_noise', _D), ('sensor_row', _I), ('tick0', _I), ('t_max', ctypes.c_double),
                 ('max_steps', ctypes.c_int32), ('lanes_per_wave', ctypes.c_int32),
                 ('fitness', _D), ('length_steps', _I), ('length_t', _D), ('cost_steps', _I),
                 ('actions', _D), ('states', _D), ('rewards', _D), ('transitions', _F)]
@@ -54,7 +54,7 @@ def make_build_desc(build):
 
 
 def rollout(weights, net, member_of_episode, ref, *, build='h2000_v90', faults=None, err0=None,
-            tick0=None, action_noise=None, noise_row=None, t_max=80.0, traces=False, transitions=False, threads=1):
+            tick0=None, action_noise=None, noise_row=None, sensor_noise=None, sensor_row=None, t_max=80.0, traces=False, transitions=False, threads=1):
     """Run episodes on the CPU oracle.
 
     weights [n_members, P] f32 (packed state_dict order); net = dict(state_dim, action_dim, hidden,
@@ -91,6 +91,15 @@ def rollout(weights, net, member_of_episode, ref, *, build='h2000_v90', faults=N
     if tick0 is not None:
         tk = np.ascontiguousarray(tick0, dtype=np.int32).reshape(n_ep)
         d.tick0 = tk.ctypes.data_as(_I); keep.append(tk)
+    if sensor_noise is not None:
+        sn = np.ascontiguousarray(sensor_noise, dtype=np.float64).reshape(-1, T + 1, 7)
+        d.sensor_noise = sn.ctypes.data_as(_D); keep.append(sn)
+        if sensor_row is not None:
+            sr = np.ascontiguousarray(sensor_row, dtype=np.int32).reshape(n_ep)
+            assert sr.max() < sn.shape[0]
+            d.sensor_row = sr.ctypes.data_as(_I); keep.append(sr)
+        else:
+            assert sn.shape[0] == n_ep
     if action_noise is not None:
         an = np.ascontiguousarray(action_noise, dtype=np.float64).reshape(-1, T, 3)
         d.action_noise = an.ctypes.data_as(_D); keep.append(an)

@@ -139,6 +139,13 @@ int serl_param_count(int S, int H, int L, int A) { return H * S + H + L * (H * H
 
 static double clipd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+/* envs/noise/citation.py:71-82 (== envs/gust/citation.py:72-86): out[:3] += .., out[4] += .., out[5] += .., out[6:8] += ..;
+ * the seven addends (bias + sd * randn, drawn by the caller in that order) arrive pre-computed */
+static void add_sensor_noise(double *x, const double *sn)
+{
+  x[0] += sn[0]; x[1] += sn[1]; x[2] += sn[2]; x[4] += sn[3]; x[5] += sn[4]; x[6] += sn[5]; x[7] += sn[6];
+}
+
 static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, int e, CitInstance *I, float *hbuf)
 {
   const double PI = 3.14159265358979323846;
@@ -152,6 +159,11 @@ static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, in
   const serl_fault_row *f = d->faults ? &d->faults[e] : &nominal;
   const float *w = d->weights + (size_t)d->member_of_episode[e] * d->weight_stride;
   const double *ref = d->ref + (size_t)e * d->ref_stride;
+  const double *snoise = NULL;                         /* this episode's row of pre-drawn sensor noise, if any */
+  if (d->sensor_noise) {
+    const int sr = d->sensor_row ? d->sensor_row[e] : e;
+    if (sr >= 0) snoise = d->sensor_noise + (size_t)sr * ((size_t)d->max_steps + 1) * 7;
+  }
   const double *noise = NULL;                          /* this episode's row of pre-drawn action noise, if any */
   if (d->action_noise) {
     const int nr = d->noise_row ? d->noise_row[e] : e;
@@ -168,6 +180,7 @@ static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, in
   cmd[1] = clipd(cmd[1], -f->ail_clip, f->ail_clip);
   if (f->rudder_jam_on != 0.0) cmd[2] = f->rudder_jam;
   cit_step(I, cmd, x);
+  if (snoise) add_sensor_noise(x, snoise);             /* envs/noise/citation.py:71-82 on the value step() returns */
   const double V0 = x[3];
   double t = 0.0;
   if (d->err0) for (int i = 0; i < 3; ++i) err[i] = d->err0[(size_t)e * 3 + i];
@@ -198,6 +211,7 @@ static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, in
     cmd[1] = clipd(u[1], -f->ail_clip, f->ail_clip);
     cmd[2] = (f->rudder_jam_on != 0.0) ? f->rudder_jam : u[2];
     cit_step(I, cmd, x);
+    if (snoise) add_sensor_noise(x, snoise + (size_t)(k + 1) * 7);
     /* reward (phlabenv.py:347-367): reference at the pre-increment time */
     const double *rk = ref + (size_t)k * 3;
     err[0] = rk[0] - x[7]; err[1] = rk[1] - x[6]; err[2] = rk[2] - x[5];

@@ -29,7 +29,36 @@ MODES = {
     'cg-for': ('cg_for', NOMINAL_ROW),
     'cg-shift': ('cg_timed', NOMINAL_ROW), 'cg-timed': ('cg_timed', NOMINAL_ROW),
     'gust': ('gust', NOMINAL_ROW),
+    'noise': ('h2000_v90', NOMINAL_ROW),                # the nominal binary behind the sensor model of envs/noise/citation.py
 }
+# modes whose SWIG wrapper adds the sensor model to what step() returns (envs/noise/citation.py:71-82,
+# envs/gust/citation.py:72-86); the evaluator feeds the kernel a pre-drawn table (sensor_noise_table)
+SENSOR_NOISE_MODES = ('noise', 'gust')
+
+
+def mode_key(mode):
+    m = mode
+    if m.lower().startswith('phlab_'):
+        m = m.split('_', 2)[2]
+    return m.lower()
+
+
+def has_sensor_noise(mode):
+    return mode_key(mode) in SENSOR_NOISE_MODES
+
+
+def sensor_noise_table(n_steps, rng=np.random):
+    """f64 [n_steps + 1, 7]: the addends of the reference's sensor model for one episode -- entry 0 for the step reset()
+    takes, entry k + 1 for env step k -- for the channels p q r | alpha | beta | phi theta, drawn in the wrapper's
+    order (randn(3), randn(1), randn(1), randn(2) per call of step(); one randn(n, 7) block of the same legacy
+    generator yields the same stream) and combined with the wrapper's own expressions."""
+    z = rng.randn(n_steps + 1, 7)
+    t = np.empty_like(z)
+    t[:, 0:3] = 3.0 * 10**(-5) + 6.3 * 10**(-4) * z[:, 0:3]
+    t[:, 3] = 4.0 * 10**(-10) * z[:, 3]
+    t[:, 4] = 1.8 * 10**(-3) + 2.7 * 10**(-4) * z[:, 4]
+    t[:, 5:7] = 4.0 * 10**(-3) + 3.2 * 10**(-5) * z[:, 5:7]
+    return t
 
 _index = None
 _cache = {}

@@ -81,8 +81,8 @@ class RolloutEngine:
 
     # ------------------------------------------------------------------------------------------
     def rollout(self, weights, spec: NetSpec, member_of_episode, ref, *, build='h2000_v90', faults=None,
-                err0=None, tick0=None, action_noise=None, noise_row=None, t_max=80.0, traces=False, transitions=False,
-                lanes_per_wave=0, sync=True):
+                err0=None, tick0=None, action_noise=None, noise_row=None, sensor_noise=None, sensor_row=None, t_max=80.0, traces=False,
+                transitions=False, lanes_per_wave=0, sync=True):
         """Low-level: run len(member_of_episode) episodes.  weights f32 [M, >=P] (device or host),
         ref f64 [E, T, 3] or [T, 3] radians.  Returns dict of device tensors."""
         dev = self.device
@@ -117,6 +117,16 @@ class RolloutEngine:
         if tick0 is not None:
             tk = torch.as_tensor(np.asarray(tick0, dtype=np.int32).reshape(E)).to(dev).contiguous()
             d.tick0 = tk.data_ptr(); keep.append(tk)
+        if sensor_noise is not None:     # [rows, T + 1, 7] (builds.sensor_noise_table); sensor_row[e] = row, -1 = none
+            sn = torch.as_tensor(sensor_noise, dtype=torch.float64).to(dev).contiguous()
+            assert sn.dim() == 3 and sn.shape[1:] == (T + 1, 7), sn.shape
+            if sensor_row is None:
+                assert sn.shape[0] == E
+            else:
+                sr = torch.as_tensor(np.asarray(sensor_row), dtype=torch.int32).to(dev).contiguous()
+                assert sr.numel() == E and int(sr.max()) < sn.shape[0]
+                d.sensor_row = sr.data_ptr(); keep.append(sr)
+            d.sensor_noise = sn.data_ptr(); keep.append(sn)
         if action_noise is not None:
             an = torch.as_tensor(action_noise, dtype=torch.float64).to(dev).contiguous()
             if noise_row is None:
@@ -186,7 +196,8 @@ def _as_weights(actors, spec):
 
 def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, smooth_fitness=False,
                  spec: Optional[NetSpec] = None, engine: Optional[RolloutEngine] = None, traces=False,
-                 transitions=False, err0=None, tick0=None, lanes_per_wave=0, need_smoothness=True) -> PopResult:
+                 transitions=False, err0=None, tick0=None, lanes_per_wave=0, need_smoothness=True,
+                 sensor_rng=None) -> PopResult:
     """Evaluate a whole population: `num_evals` episodes per member (agent.py:229-256).
 
     actors : sequence of Actor / GeneticAgent, or a packed f32 tensor [pop, P] (then pass `spec`)
@@ -197,6 +208,9 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
     tick0  : i32 [pop*num_evals] model clock each episode starts with (None = 0).  The reference's initialize()
              does not reset the model clock, so in its sequential loop episode j of a process starts at
              tick = sum over earlier episodes of (steps + 1); only the time-switched builds (cg-shift, gust) care.
+    sensor_rng : modes 'noise' / 'gust' add the reference's sensor model to what step() returns; its randn draws
+             come from this legacy generator (None = np.random, like the wrappers), one block of T + 1 steps per
+             noisy episode in episode order, up front (builds.sensor_noise_table)
     Episode order is member-major: e = member*num_evals + eval  (the reference's loop nest)."""
     engine = engine or default_engine()
     if spec is None:
@@ -219,6 +233,9 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
     err0 = None if err0 is None else np.asarray(err0, dtype=np.float64).reshape(E, 3)
     # one kernel launch per dynamics build (be/jr/sa/se share the nominal build as per-episode fault rows; cg, ice,
     # cg-shift ... are builds of their own); launches are stream-ordered and their results scattered back
+    T_ref = refs.shape[-2]
+    sensor = {e: builds.sensor_noise_table(T_ref, sensor_rng if sensor_rng is not None else np.random)
+              for e in range(E) if builds.has_sensor_noise(modes[e])}
     groups = {}
     for e, (b, _) in enumerate(resolved):
         groups.setdefault(b, []).append(e)
@@ -228,9 +245,15 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
         rows = [resolved[e][1] for e in idx]
         faults = np.array(rows, dtype=np.float64) if any(r != builds.NOMINAL_ROW for r in rows) else None
         whole = len(idx) == E
+        sn = sr = None
+        noisy = [e for e in idx if e in sensor]
+        if noisy:
+            sn = np.stack([sensor[e] for e in noisy])
+            pos = {e: j for j, e in enumerate(noisy)}
+            sr = np.array([pos.get(e, -1) for e in idx], dtype=np.int32)
         o = engine.rollout(w, spec, moe[idx], refs if (whole or refs.dim() == 2) else refs[torch.as_tensor(idx)], build=b,
                            faults=faults, err0=None if err0 is None else err0[idx],
-                           tick0=None if tick0 is None else tick0[idx], t_max=t_max,
+                           tick0=None if tick0 is None else tick0[idx], t_max=t_max, sensor_noise=sn, sensor_row=sr,
                            traces=want, transitions=transitions, lanes_per_wave=lanes_per_wave)
         kernel_ms += engine.last_kernel_ms
         if whole:
@@ -330,7 +353,9 @@ def make_evaluate(args, *, mode='nominal', t_max=20, ref_fn=None, engine=None, r
             # agent.py:90-93, drawn up-front in the same order the reference draws it per step
             noise = np.clip(args.noise_sd * np.random.randn(T, 3), -args.noise_clip, args.noise_clip)[None]
         build, row = builds.resolve_mode(mode)
-        out = engine.rollout(pack_population([actor]), spec, [0], ref, build=build,
+        # sensor model of the 'noise' / 'gust' wrappers: np.random, like the reference, one block per episode up front
+        sn = builds.sensor_noise_table(T, np.random)[None] if builds.has_sensor_noise(mode) else None
+        out = engine.rollout(pack_population([actor]), spec, [0], ref, build=build, sensor_noise=sn,
                              faults=None if row == builds.NOMINAL_ROW else [row], err0=state['err'][None], tick0=[state['tick']],
                              action_noise=noise, t_max=t_max, traces=True, transitions=store_transition)
         n = int(out['length_steps'][0])

@@ -84,7 +84,7 @@ def test_faults_and_trims_vs_reference_python(golden, tolerances):
     g = golden('faults')
     w = golden('actors')['serl50'][[18, 0, 7]]
     ref = golden('ref_base')['ref']
-    # 'gust' / 'noise' are not comparable: their wrappers (envs/gust/citation.py:72-86) add np.random sensor noise
+    # 'gust' / 'noise' draw np.random sensor noise in their wrappers: test_sensor_noise_wrappers_vs_reference_python
     for mode in ['be', 'jr', 'sa', 'se', 'ice', 'cg', 'cg-for', 'high-q', 'low-q', 'cg-shift']:
         build, row = builds.resolve_mode(mode)
         # the golden episodes ran one after the other on ONE env object per mode, and the reference's initialize()
@@ -184,3 +184,37 @@ def test_action_noise_path_and_table_exhaustion():
     m = R.rollout(w, NET['serl50'], [0, 0, 0], ref, t_max=20, action_noise=noise, noise_row=[-1, 0, -1])
     assert m['fitness'][0] == a['fitness'][0] == m['fitness'][2] and m['fitness'][1] == b['fitness'][0]
     assert (m['length_steps'] == [a['length_steps'][0], b['length_steps'][0], a['length_steps'][0]]).all()
+
+
+def _sensor_case(golden, mode):
+    from serl_amd import builds
+    g = golden('sensor_noise')
+    ref = golden('ref_base')['ref']
+    build, row = builds.resolve_mode(mode)
+    # the wrapper draws randn(3), randn(1), randn(1), randn(2) per step() from the seeded legacy generator
+    sn = np.stack([builds.sensor_noise_table(len(ref), np.random.RandomState(int(g['seed_%s_%d' % (mode, i)])))
+                   for i in (18, 0, 7)])
+    # the episodes ran one after the other on one library instance: the model clock keeps running (gust is time-switched)
+    tick0 = [int(sum(g['%s_%d' % (mode, i)][3] + 1 for i in (18, 0, 7)[:j])) for j in range(3)]
+    return g, ref, build, sn, tick0
+
+
+@pytest.mark.parametrize('mode', ['noise', 'gust'])
+def test_sensor_noise_wrappers_vs_reference_python(golden, mode):
+    """envs/noise/citation.py:71-82 and envs/gust/citation.py:72-86 add a sensor model (bias + sd * np.random.randn) to
+    what step() returns.  Golden: the reference's own CitationEnv / Agent.evaluate / wrappers with np.random seeded
+    before every episode (tests/golden/make_sensor_golden.py); here the same draws arrive as a pre-drawn table."""
+    from oracle import rollout as R
+    g, ref, build, sn, tick0 = _sensor_case(golden, mode)
+    w = golden('actors')['serl50'][[18, 0, 7]]
+    o = R.rollout(w, NET['serl50'], [0, 1, 2], ref, build=build, sensor_noise=sn, tick0=tick0, t_max=80, threads=3)
+    clean = R.rollout(w, NET['serl50'], [0, 1, 2], ref, build=build, tick0=tick0, t_max=80, threads=3)
+    for j, i in enumerate((18, 0, 7)):
+        ref_fit, ref_len, ref_sm, ref_n = g['%s_%d' % (mode, i)]
+        assert o['length_steps'][j] == int(ref_n) and o['length_t'][j] == ref_len
+        np.testing.assert_allclose(o['fitness'][j], ref_fit, rtol=RTOL, err_msg='%s %d' % (mode, i))
+        assert abs(clean['fitness'][j] - ref_fit) > 1e-3 * abs(ref_fit)        # the sensor model is not a no-op
+    # per-episode rows: an episode without a row is the clean episode
+    m = R.rollout(w, NET['serl50'], [0, 1, 2], ref, build=build, sensor_noise=sn[[1]], sensor_row=[-1, 0, -1], tick0=tick0,
+                  t_max=80, threads=3)
+    assert m['fitness'][0] == clean['fitness'][0] and m['fitness'][1] == o['fitness'][1] and m['fitness'][2] == clean['fitness'][2]
