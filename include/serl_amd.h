@@ -107,6 +107,11 @@ typedef struct serl_rollout_desc {
                                        episode can have a CU of its own (episodes <= CUs), one wavefront per
                                        episode beyond; 1..64 = lane-per-episode kernels with that many episodes
                                        per wavefront (nominal / ice code variants only) */
+  int32_t concurrent_episodes;      /* episodes of OTHER serl_rollout calls expected to run at the same time on other
+                                       streams (mixed-build sweeps: one call per dynamics build); the kernel and the
+                                       wavefronts per workgroup are chosen for n_episodes + concurrent_episodes so that
+                                       the launches fit the GPU side by side.  0 = this call has the GPU to itself */
+  int32_t pad_;
   /* -- results (per episode) */
   double *fitness;                  /* sum of rewards incl. termination penalty */
   int32_t *length_steps;            /* number of env steps taken */

@@ -22,6 +22,7 @@ class RolloutDesc(ctypes.Structure):
                 ('member_of_episode', _I), ('faults', _D), ('ref', _D), ('ref_stride', ctypes.c_int64),
                 ('err0', _D), ('action_noise', _D), ('noise_row', _I), ('sensor_noise', _D), ('sensor_row', _I), ('tick0', _I), ('t_max', ctypes.c_double),
                 ('max_steps', ctypes.c_int32), ('lanes_per_wave', ctypes.c_int32),
+                ('concurrent_episodes', ctypes.c_int32), ('pad_', ctypes.c_int32),
                 ('fitness', _D), ('length_steps', _I), ('length_t', _D), ('cost_steps', _I),
                 ('actions', _D), ('states', _D), ('rewards', _D), ('transitions', _F)]
 

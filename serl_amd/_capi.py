@@ -26,6 +26,7 @@ class RolloutDesc(ctypes.Structure):
                 ('member_of_episode', VP), ('faults', VP), ('ref', VP), ('ref_stride', ctypes.c_int64),
                 ('err0', VP), ('action_noise', VP), ('noise_row', VP), ('sensor_noise', VP), ('sensor_row', VP), ('tick0', VP), ('t_max', ctypes.c_double),
                 ('max_steps', ctypes.c_int32), ('lanes_per_wave', ctypes.c_int32),
+                ('concurrent_episodes', ctypes.c_int32), ('pad_', ctypes.c_int32),
                 ('fitness', VP), ('length_steps', VP), ('length_t', VP), ('cost_steps', VP),
                 ('actions', VP), ('states', VP), ('rewards', VP), ('transitions', VP)]
 

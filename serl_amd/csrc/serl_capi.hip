@@ -227,27 +227,32 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     a.prof = c->prof;
   }
   int lanes = d->lanes_per_wave;
-  if (lanes <= 0 && serl_use_team(s.code, d->n_episodes)) {
+  // launches that share the GPU with others run on streams of their own: the context's one pair of timing events is
+  // not recorded for them (an event in flight on one stream must not be re-recorded on another)
+  const bool timed = d->concurrent_episodes <= 0;
+  const int together = d->n_episodes + (d->concurrent_episodes > 0 ? d->concurrent_episodes : 0);   // episodes sharing the GPU
+  if (lanes <= 0 && serl_use_team(s.code, together)) {
     a.lanes = 1;
     a.block = 128;
-    HIP_TRY(hipEventRecord(c->ev0, stream));
+    if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
     serl_launch_rollout_team(s.code, a, d->n_episodes, stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev1, stream));
-    c->timed = true;
+    if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
+    c->timed = timed;
     return SERL_OK;
   }
   if (lanes <= 0 && serl_has_wave_kernel(s.code)) {
     // default: one wavefront per episode (model glue wave-uniform, look-ups / actor rows / ODE5 states per lane)
-    const int wpb = serl_wave_kernel_waves_per_block(d->n_episodes);
+    // side-by-side launches round their workgroup counts up separately: leave room for a few partial workgroups
+    const int wpb = serl_wave_kernel_waves_per_block(together + (timed ? 0 : 16));
     a.lanes = 1;
     a.block = 64 * wpb;
     const int grid = (d->n_episodes + wpb - 1) / wpb;
-    HIP_TRY(hipEventRecord(c->ev0, stream));
+    if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
     serl_launch_rollout_wave(s.code, a, grid, stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev1, stream));
-    c->timed = true;
+    if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
+    c->timed = timed;
     return SERL_OK;
   }
   if (!serl_has_lane_kernel(s.code))
@@ -265,12 +270,12 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   const int wpb = serl_waves_per_block(waves);
   a.block = 64 * wpb;
   const int grid = (waves + wpb - 1) / wpb;
-  HIP_TRY(hipEventRecord(c->ev0, stream));
+  if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
   if (s.code == SERL_DYN_NOMINAL) serl_launch_rollout_nominal(a, grid, stream);
   else serl_launch_rollout_ice(a, grid, stream);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(c->ev1, stream));
-  c->timed = true;
+  if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
+  c->timed = timed;
   return SERL_OK;
 }
 

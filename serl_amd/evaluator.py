@@ -53,6 +53,9 @@ class RolloutEngine:
         _capi.check(self.lib.serl_ctx_create(self.device.index, ctypes.byref(h)), 'serl_ctx_create')
         self.ctx = h
         self.slots = {}
+        # side streams for mixed-build evaluations, made up front: the runtime binds a stream to one of its few hardware
+        # queues when it is created, and streams made back to back land on different ones (measured: profiles/r01_g_mixed.md)
+        self._side = [torch.cuda.Stream(self.device) for _ in range(3)]
         self.last_kernel_ms = 0.0
 
     def close(self):
@@ -65,6 +68,13 @@ class RolloutEngine:
             self.close()
         except Exception:
             pass
+
+    def side_stream(self, i):
+        """i-th side stream of this engine (mixed-build evaluations run one launch per dynamics build side by side);
+        created once: a HIP stream is bound to a hardware queue when it is made"""
+        while len(self._side) <= i:
+            self._side.append(torch.cuda.Stream(self.device))
+        return self._side[i]
 
     def slot_of(self, build):
         data, ent = builds.load(build)
@@ -82,7 +92,7 @@ class RolloutEngine:
     # ------------------------------------------------------------------------------------------
     def rollout(self, weights, spec: NetSpec, member_of_episode, ref, *, build='h2000_v90', faults=None,
                 err0=None, tick0=None, action_noise=None, noise_row=None, sensor_noise=None, sensor_row=None, t_max=80.0, traces=False,
-                transitions=False, lanes_per_wave=0, sync=True):
+                transitions=False, lanes_per_wave=0, sync=True, concurrent_episodes=0):
         """Low-level: run len(member_of_episode) episodes.  weights f32 [M, >=P] (device or host),
         ref f64 [E, T, 3] or [T, 3] radians.  Returns dict of device tensors."""
         dev = self.device
@@ -105,6 +115,7 @@ class RolloutEngine:
                               build_slot=self.slot_of(build), member_of_episode=moe.data_ptr(),
                               ref=ref_t.data_ptr(), ref_stride=0 if shared else T * 3, t_max=float(t_max),
                               max_steps=T, lanes_per_wave=int(lanes_per_wave),
+                              concurrent_episodes=int(concurrent_episodes),
                               fitness=out['fitness'].data_ptr(), length_steps=out['length_steps'].data_ptr(),
                               length_t=out['length_t'].data_ptr(), cost_steps=out['cost_steps'].data_ptr())
         keep = [w, moe, ref_t]
@@ -197,7 +208,7 @@ def _as_weights(actors, spec):
 def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, smooth_fitness=False,
                  spec: Optional[NetSpec] = None, engine: Optional[RolloutEngine] = None, traces=False,
                  transitions=False, err0=None, tick0=None, lanes_per_wave=0, need_smoothness=True,
-                 sensor_rng=None) -> PopResult:
+                 sensor_rng=None, concurrent=True) -> PopResult:
     """Evaluate a whole population: `num_evals` episodes per member (agent.py:229-256).
 
     actors : sequence of Actor / GeneticAgent, or a packed f32 tensor [pop, P] (then pass `spec`)
@@ -208,6 +219,7 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
     tick0  : i32 [pop*num_evals] model clock each episode starts with (None = 0).  The reference's initialize()
              does not reset the model clock, so in its sequential loop episode j of a process starts at
              tick = sum over earlier episodes of (steps + 1); only the time-switched builds (cg-shift, gust) care.
+    concurrent : False = the per-build launches run one after the other (A/B switch)
     sensor_rng : modes 'noise' / 'gust' add the reference's sensor model to what step() returns; its randn draws
              come from this legacy generator (None = np.random, like the wrappers), one block of T + 1 steps per
              noisy episode in episode order, up front (builds.sensor_noise_table)
@@ -240,6 +252,14 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
     for e, (b, _) in enumerate(resolved):
         groups.setdefault(b, []).append(e)
     out, kernel_ms = None, 0.0
+    # several builds: their launches run side by side on streams of their own (the library sizes each launch for the
+    # episodes of all of them: `concurrent_episodes`), joined on the caller's stream afterwards
+    many = len(groups) > 1 and concurrent
+    cur = torch.cuda.current_stream(engine.device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if many:
+        ev0.record(cur)
+    parts = []
     for b, idx in groups.items():
         idx = np.asarray(idx)
         rows = [resolved[e][1] for e in idx]
@@ -251,23 +271,44 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
             sn = np.stack([sensor[e] for e in noisy])
             pos = {e: j for j, e in enumerate(noisy)}
             sr = np.array([pos.get(e, -1) for e in idx], dtype=np.int32)
-        o = engine.rollout(w, spec, moe[idx], refs if (whole or refs.dim() == 2) else refs[torch.as_tensor(idx)], build=b,
-                           faults=faults, err0=None if err0 is None else err0[idx],
-                           tick0=None if tick0 is None else tick0[idx], t_max=t_max, sensor_noise=sn, sensor_row=sr,
-                           traces=want, transitions=transitions, lanes_per_wave=lanes_per_wave)
-        kernel_ms += engine.last_kernel_ms
+        side = engine.side_stream(len(parts)) if many else cur
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            o = engine.rollout(w, spec, moe[idx], refs if (whole or refs.dim() == 2) else refs[torch.as_tensor(idx)], build=b,
+                               faults=faults, err0=None if err0 is None else err0[idx],
+                               tick0=None if tick0 is None else tick0[idx], t_max=t_max, sensor_noise=sn, sensor_row=sr,
+                               traces=want, transitions=transitions, lanes_per_wave=lanes_per_wave, sync=not many,
+                               concurrent_episodes=(E - len(idx)) if many else 0)
         if whole:
             out = o
+            kernel_ms = engine.last_kernel_ms
             break
-        if out is None:
-            out = {}
-        ti = torch.as_tensor(idx, device=o['fitness'].device)
-        for k, v in o.items():
-            if not torch.is_tensor(v):
-                continue
-            if k not in out:
-                out[k] = torch.zeros((E,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
-            out[k][ti] = v
+        if not many:
+            kernel_ms += engine.last_kernel_ms
+        else:
+            for v in o.values():
+                if torch.is_tensor(v):
+                    v.record_stream(cur)
+        parts.append((idx, o, side))
+    if parts:
+        for _, _, side in parts:
+            cur.wait_stream(side)
+        ev1.record(cur)
+        out = {}
+        for idx, o, _ in parts:
+            ti = torch.as_tensor(idx, device=o['fitness'].device)
+            for k, v in o.items():
+                if not torch.is_tensor(v):
+                    continue
+                if k not in out:
+                    out[k] = torch.zeros((E,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+                out[k][ti] = v
+        if many:
+            ev1.synchronize()
+            kernel_ms = ev0.elapsed_time(ev1)          # all launches of the evaluation, side by side
+        if bool((out['length_steps'] < 0).any()):
+            raise RuntimeError('reference table too short: %d episodes were still running after %d steps'
+                               % (int((out['length_steps'] < 0).sum()), T_ref))
     engine.last_kernel_ms = kernel_ms
     ret = out['fitness'].cpu().numpy()
     ls = out['length_steps'].cpu().numpy()
