@@ -106,6 +106,44 @@ static __device__ __forceinline__ float serl_bcast(float v, int srclane)
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
 }
 
+// A v_readlane result lands in an SGPR that the next VALU instruction may not read for two wait states; read one by
+// one, every broadcast is followed by an s_nop (measured: 67 of them in one 505-instruction layer body).  Reading eight
+// lanes into eight SGPRs first and consuming them afterwards fills those slots with useful instructions; the order of
+// the floating-point operations is unchanged.
+template <int N>
+static __device__ __forceinline__ float serl_sum_lanes(float s, float v)      // s + v[0] + v[1] + ... + v[N-1], in index order
+{
+  static_assert(N % 8 == 0, "batches of eight lanes");
+#pragma unroll
+  for (int j0 = 0; j0 < N; j0 += 8) {
+    float b[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) b[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j0 + q));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s = s + b[q];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return s;
+}
+
+template <int N>
+static __device__ __forceinline__ float serl_mac_lanes(float acc, const float (&row)[N], float h)   // acc += row[j] * h[j], j ascending
+{
+  static_assert(N % 8 == 0, "batches of eight lanes");
+#pragma unroll
+  for (int j0 = 0; j0 < N; j0 += 8) {
+    float b[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) b[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), j0 + q));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc = acc + row[j0 + q] * b[q];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return acc;
+}
+
 typedef const __attribute__((address_space(1))) float *serl_gptr;   // weights live in global memory (HBM/L2)
 typedef float serl_v4f __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) serl_v4f *serl_gptr4;
@@ -287,18 +325,13 @@ static __device__ void serl_actor_forward_small(const serl_rollout_desc &dd, con
     float acc = nbi;
     const float gm = ngm, bt = nbt;
     if (l < L) issue(l + 1);
-#pragma unroll
-    for (int j = 0; j < H; ++j) acc = acc + row[j] * serl_bcast(h, j);
+    acc = serl_mac_lanes<H>(acc, row, h);
     CITW_T(23);
     if (l < L) {
-      float mean = 0.0f;
-#pragma unroll
-      for (int j = 0; j < H; ++j) mean = mean + serl_bcast(acc, j);
+      float mean = serl_sum_lanes<H>(0.0f, acc);
       mean = mean / (float)H;
       const float d = acc - mean, dd2 = d * d;
-      float var = 0.0f;
-#pragma unroll
-      for (int j = 0; j < H; ++j) var = var + serl_bcast(dd2, j);
+      const float var = serl_sum_lanes<H>(0.0f, dd2);
       const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
       h = serl_act(gm * d / den + bt, act);
     } else {
@@ -406,18 +439,13 @@ static __device__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const
     float acc = nbi;
     const float gm = ngm, bt = nbt;
     if (l < L) issue(l + 1);
-#pragma unroll
-    for (int j = 0; j < H; ++j) acc = acc + row[j] * serl_bcast(h, j);
+    acc = serl_mac_lanes<H>(acc, row, h);
     CITW_T(23);
     if (l < L) {
-      float mean = 0.0f;
-#pragma unroll
-      for (int j = 0; j < H; ++j) mean = mean + serl_bcast(acc, j);
+      float mean = serl_sum_lanes<H>(0.0f, acc);
       mean = mean / (float)H;
       const float d = acc - mean, dd2 = d * d;
-      float var = 0.0f;
-#pragma unroll
-      for (int j = 0; j < H; ++j) var = var + serl_bcast(dd2, j);
+      const float var = serl_sum_lanes<H>(0.0f, dd2);
       const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
       h = serl_act(gm * d / den + bt, act);
     } else {
