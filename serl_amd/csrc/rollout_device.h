@@ -165,7 +165,15 @@ static __device__ __forceinline__ float serl_mac_chunk(float acc, const float (&
 {
   if (jc + 32 <= H) {
 #pragma unroll
-    for (int q = 0; q < 32; ++q) acc = acc + wv[q] * serl_bcast(hsrc, jb + q);
+    for (int q0 = 0; q0 < 32; q0 += 8) {        // eight broadcasts, then their multiply-adds (see serl_sum_lanes)
+      float b[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) b[q] = serl_bcast(hsrc, jb + q0 + q);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc = acc + wv[q0 + q] * b[q];
+      __builtin_amdgcn_sched_barrier(0);
+    }
   } else {
 #pragma unroll
     for (int q4 = 0; q4 < 8; ++q4) {
@@ -181,8 +189,17 @@ static __device__ __forceinline__ float serl_mac_chunk(float acc, const float (&
 // sum of the first n row values in index order (every lane computes the same sum)
 static __device__ __forceinline__ float serl_seq_sum(float s, float v, int n)
 {
-#pragma unroll 8
-  for (int i = 0; i < n; ++i) s = s + serl_bcast(v, i);
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {                   // eight broadcasts, then their additions (see serl_sum_lanes)
+    float b[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) b[q] = serl_bcast(v, i + q);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s = s + b[q];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (; i < n; ++i) s = s + serl_bcast(v, i);
   return s;
 }
 
