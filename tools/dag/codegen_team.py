@@ -30,6 +30,7 @@ TEAM_WAVES = int(os.environ.get('CITW_TEAM_WAVES', 4))
 # instruction estimates used by the balancer (wave 0's fixed work: search + 2-D + 1-D passes; later look-up rounds)
 LOOKUP_PHASES = int(os.environ.get('CITW_TEAM_LOOKUP_COST', 1400))
 POST_ROUND2_COST = int(os.environ.get('CITW_TEAM_ROUND2_COST', 300))
+AFFINITY = float(os.environ.get('CITW_TEAM_AFFINITY', 0.0))
 CW = dict(div=11, sqrt=15, sel=3, unord=2, table3=120)
 FN = dict(sc_sin=100, sc_cos=100, sin=100, cos=100, tan=120, exp=40, log10=60, log=60, atan=80, pow=250)
 
@@ -87,7 +88,8 @@ class TeamGen(codegen.Gen):
             for b in range(K):
                 add = [m for m in cones[n] if m not in have[b]]
                 res.append(load[b] + sum(cost(m) for m in add) + fn_cost(add, b))
-            b = min(range(K), key=lambda q: (res[q], q))
+            # AFFINITY > 0 leans towards the wave that already holds most of the cone (less recomputation overall)
+            b = min(range(K), key=lambda q: (res[q] + AFFINITY * (res[q] - load[q]), q))
             add = [m for m in cones[n] if m not in have[b]]
             load[b] = res[b]
             fn_cost(add, b, True)
