@@ -30,7 +30,9 @@ TEAM_WAVES = int(os.environ.get('CITW_TEAM_WAVES', 4))
 # instruction estimates used by the balancer (wave 0's fixed work: search + 2-D + 1-D passes; later look-up rounds)
 LOOKUP_PHASES = int(os.environ.get('CITW_TEAM_LOOKUP_COST', 1400))
 POST_ROUND2_COST = int(os.environ.get('CITW_TEAM_ROUND2_COST', 300))
-AFFINITY = float(os.environ.get('CITW_TEAM_AFFINITY', 0.0))
+IMPORT_COST = float(os.environ.get('CITW_TEAM_IMPORT_COST', 0.0))         # units per value a wave fetches from LDS behind B1
+AFFINITY_POST = float(os.environ.get('CITW_TEAM_AFFINITY_POST', 0.0))
+AFFINITY = float(os.environ.get('CITW_TEAM_AFFINITY', 2.0))            # > 0: a sink leans towards the wave that already holds most of its cone
 CW = dict(div=11, sqrt=15, sel=3, unord=2, table3=120)
 FN = dict(sc_sin=100, sc_cos=100, sin=100, cos=100, tan=120, exp=40, log10=60, log=60, atan=80, pow=250)
 
@@ -102,11 +104,19 @@ class TeamGen(codegen.Gen):
         psinks = [n for n in roots if n in post]
         pcones = {n: self.closure([n], post) for n in psinks}
         phave = [set() for _ in range(K)]
+        pins = [set() for _ in range(K)]          # what a wave fetches from LDS behind B1: look-up results, values of other waves
         pload = [POST_ROUND2_COST if self.nrounds > 1 else 0] + [0] * (K - 1)
         powner = {}
+        fetched = lambda cone: set(c for m in cone for c in build_dag.children(g, m) if c not in post and g.nodes[c][0] not in LEAF)
+
+        def pcost(n, b):
+            new = [m for m in pcones[n] if m not in phave[b]]
+            ins = [c for c in fetched(new) if c not in pins[b] and not (c in have[b] and g.nodes[c][0] not in LOOKUPS)]
+            return sum(cost(m) for m in new) + IMPORT_COST * len(ins), ins
         for n in sorted(psinks, key=lambda n: (-sum(cost(m) for m in pcones[n]), n)):
-            res = [pload[b] + sum(cost(m) for m in pcones[n] if m not in phave[b]) for b in range(K)]
-            b = 0 if self.rnd[n] >= 2 else min(range(K), key=lambda q: (res[q], q))
+            res = [pload[b] + pcost(n, b)[0] for b in range(K)]
+            b = 0 if self.rnd[n] >= 2 else min(range(K), key=lambda q: (res[q] + AFFINITY_POST * (res[q] - pload[q]), q))
+            pins[b].update(pcost(n, b)[1])
             phave[b].update(pcones[n]); pload[b] = res[b]; powner[n] = b
         self.post, self.phave, self.powner, self.post_load = post, phave, powner, pload
         self.post_sinks = [[n for n in psinks if powner[n] == b] for b in range(K)]
@@ -189,7 +199,8 @@ class TeamGen(codegen.Gen):
             elif b == 1:
                 TM = lambda k: 'CITW_U(%d)' % (10 + k)
             else:
-                TM = lambda k: '((void)0)'
+                slots = {2: {0: 15, 1: 16, 2: 17, 3: 18}, 3: {0: 19, 1: 21, 2: 24, 3: 25}}.get(b, {})      # pre-B1, wait B1, post, wait B2
+                TM = lambda k: ('CITW_W(%d, %d)' % (b, slots[k])) if k in slots else '((void)0)'
 
             def emit_node(n, allowed=None):
                 stack = [(n, False)]
@@ -288,7 +299,7 @@ class TeamGen(codegen.Gen):
             B('  const bool major = stage == 0;')
             B('  double STOP = 0.0;')
             B('  const int lane = threadIdx.x & 63;')
-            B('  %s;' % ('CITW_T0()' if b == 0 else ('CITW_U0()' if b == 1 else '((void)0)')))
+            B('  %s;' % ('CITW_T0()' if b == 0 else ('CITW_U0()' if b == 1 else 'CITW_W0(%d)' % b)))
             # Derivative-block bank inputs: every wave reads the ones it needs before B1, the banks are rewritten after B1
             mine, st, seen = set(), list(self.pre_sinks[b]) + list(self.post_sinks[b]) + list(self.have[b]), set()
             st += [self.dw_out[k] for k, o in self.dw_owner.items() if o == b]
