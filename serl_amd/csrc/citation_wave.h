@@ -80,6 +80,19 @@ __shared__ unsigned long long g_tlastw[4];    // ... and for waves 2, 3 (barrier
 #define CITW_U(k) ((void)0)
 #endif
 
+// Hand-over of a look-up input from a helper wavefront to wave 0 without a barrier (team kernels): the helper stores the
+// value(s), then the sequence number of the evaluation (release); wave 0 polls the number (acquire) before it reads.
+// All wavefronts of a workgroup are resident, so the poll cannot starve the writer; numbers only grow within an episode.
+__shared__ unsigned g_flag[4];       // one per producing wavefront of the team
+static __device__ __forceinline__ void citw_flag_raise(int q, unsigned seq)
+{
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(&g_flag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+static __device__ __forceinline__ void citw_flag_wait(int q, unsigned seq)
+{
+  while (__hip_atomic_load(&g_flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(1);
+}
+
 static __device__ __forceinline__ unsigned long long citw_d2u(double d) { return (unsigned long long)__double_as_longlong(d); }
 static __device__ __forceinline__ double citw_u2d(unsigned long long u) { return __longlong_as_double((long long)u); }
 

@@ -32,6 +32,10 @@ LOOKUP_PHASES = int(os.environ.get('CITW_TEAM_LOOKUP_COST', 1400))
 POST_ROUND2_COST = int(os.environ.get('CITW_TEAM_ROUND2_COST', 300))
 IMPORT_COST = float(os.environ.get('CITW_TEAM_IMPORT_COST', 0.0))         # units per value a wave fetches from LDS behind B1
 AFFINITY_POST = float(os.environ.get('CITW_TEAM_AFFINITY_POST', 0.0))
+SHARE_LIBM = int(os.environ.get('CITW_TEAM_SHARE_LIBM', 1))           # 1: every libm call is made by one wave, the others read the result (flag hand-over)
+SPLIT_IN = int(os.environ.get('CITW_TEAM_SPLIT_INPUTS', 1))           # 1: the heaviest round-1 input cone (pow chain) runs on a helper, handed over by flag
+FN_SCALE = float(os.environ.get('CITW_TEAM_FN_SCALE', 1.0))            # libm bodies relative to the first estimates in FN
+LIBM_SCALE = float(os.environ.get('CITW_TEAM_LIBM_SCALE', 1.0))        # extra factor for the handed-over cone's libm bodies
 AFFINITY = float(os.environ.get('CITW_TEAM_AFFINITY', 2.0))            # > 0: a sink leans towards the wave that already holds most of its cone
 CW = dict(div=11, sqrt=15, sel=3, unord=2, table3=120)
 FN = dict(sc_sin=100, sc_cos=100, sin=100, cos=100, tan=120, exp=40, log10=60, log=60, atan=80, pow=250)
@@ -49,6 +53,8 @@ class TeamGen(codegen.Gen):
             if m in out or m not in within:
                 continue
             out.add(m)
+            if m in getattr(self, 'shared_libm', ()):
+                continue            # a libm result made once for the team: its argument cone belongs to the wave that makes the call
             st.extend(build_dag.children(self.g, m))
         return out
 
@@ -68,21 +74,73 @@ class TeamGen(codegen.Gen):
         sinks = [n for n in self.order if n in S0 and n not in A0 and (later_use(n) or n in rootset)]
         cost = lambda n: 0 if g.nodes[n][0] in FN else 2 * CW.get(g.nodes[n][0], 1)
         fns = [set() for _ in range(K)]
+        self.shared_libm = set(self.libm_slot) if (SHARE_LIBM and K > 1) else set()
+        shared = self.shared_libm
 
         def fn_cost(nodes, b, commit=False):
             c = 0
             for m in nodes:
                 f = g.nodes[m][0]
-                if f in FN:
+                if f in FN and m not in shared:
                     f2 = {'sc_sin': 'sincos', 'sc_cos': 'sincos', 'sin': 'sincos', 'cos': 'sincos'}.get(f, f)
                     if f2 not in fns[b]:
-                        c += FN[f]
+                        c += FN_SCALE * FN[f]
                         if commit:
                             fns[b].add(f2)
             return c
-        # ---- glue in front of the look-ups
-        have = [set(A0)] + [set() for _ in range(K - 1)]
-        load = [sum(cost(m) for m in A0) + fn_cost(A0, 0, True) + LOOKUP_PHASES] + [0] * (K - 1)
+        # ---- glue in front of the look-ups.  The cone of the heaviest round-1 look-up input -- the libm pow chain of the air
+        # data -- runs on helper wave P, which puts the input into wave 0's g_in row and raises a flag (LDS, release /
+        # acquire); wave 0 computes the other inputs meanwhile and polls the flag before the index search.  No barrier:
+        # only wave 0 ever waits, and only if P is late.
+        ins0 = [n for n in self.rounds[0]['ins']]
+        full_cone = lambda n: set(m for m in self.closure_all(n) if m in S0)
+        weight = lambda n: sum(cost(m) for m in full_cone(n)) + sum(FN.get(g.nodes[m][0], 0) for m in full_cone(n))
+        self.in_owner = {n: 0 for n in ins0}
+        self.P = None
+        if SPLIT_IN and K > 1 and ins0:
+            heavy = max(ins0, key=lambda n: (weight(n), -ins0.index(n)))
+            if any(g.nodes[m][0] in FN for m in full_cone(heavy)):
+                self.P = K - 1
+                self.in_owner[heavy] = self.P
+        A0w = self.closure([n for n in ins0 if self.in_owner[n] == 0 and n in S0], S0)       # wave 0's share of A0
+        have = [set(A0w)] + [set() for _ in range(K - 1)]
+        load = [sum(cost(m) for m in A0w) + fn_cost(A0w, 0, True) + LOOKUP_PHASES] + [0.0] * (K - 1)
+        self.handed = set()
+        if self.P is not None:
+            for n in ins0:
+                if self.in_owner[n] == self.P:
+                    self.handed |= self.closure([n], S0)
+            have[self.P] |= self.handed
+            load[self.P] += sum(cost(m) for m in self.handed) + LIBM_SCALE * fn_cost(self.handed, self.P, True)
+        # ---- who makes which libm call (shared results): the calls of the handed-over cone belong to P, the other groups
+        # (one function body each) go to the helpers, heaviest first
+        self.call_owner = {}
+        if shared:
+            grp = lambda j: self.libm_calls[j][0][0]
+            gcost = lambda f: FN_SCALE * FN[{'sincos': 'sc_sin'}.get(f, f)]
+
+            def give(b, j):
+                self.call_owner[j] = b
+                cone = self.closure([self.libm_calls[j][0][1]], S0)
+                load[b] += sum(cost(m) for m in cone if m not in have[b])
+                have[b] |= cone
+                have[b] |= set(self.libm_calls[j][1].values())
+            for j in range(len(self.libm_calls)):
+                if self.P is not None and any(nd in self.handed for nd in self.libm_calls[j][1].values()):
+                    if grp(j) not in fns[self.P]:
+                        load[self.P] += LIBM_SCALE * gcost(grp(j))
+                        fns[self.P].add(grp(j))
+                    give(self.P, j)
+            groups = collections.defaultdict(list)
+            for j in range(len(self.libm_calls)):
+                if j not in self.call_owner:
+                    groups[grp(j)].append(j)
+            helpers = list(range(1, K))
+            for f, calls in sorted(groups.items(), key=lambda kv: (-gcost(kv[0]), kv[0])):
+                b = min(helpers, key=lambda q: (load[q], q))
+                load[b] += gcost(f)
+                for j in calls:
+                    give(b, j)
         owner = {}
         cones = {n: self.closure([n], S0) for n in sinks}
         for n in sorted(sinks, key=lambda n: (-sum(cost(m) for m in cones[n]), n)):
@@ -178,6 +236,17 @@ class TeamGen(codegen.Gen):
                 self.libm_key[node] = key
                 self.libm_which[node] = which
         self.libm_slot_all = dict(self.libm_slot)
+        # shared libm results: (owner wave, slot in its g_m row) of every call result
+        self.row_slot, self.calls_of = {}, collections.defaultdict(list)
+        for j in sorted(self.call_owner):
+            self.calls_of[self.call_owner[j]].append(j)
+        for q, calls in self.calls_of.items():
+            for jl, j in enumerate(calls):
+                for which, node in self.libm_calls[j][1].items():
+                    self.row_slot[node] = (q, 2 * jl + (0 if which == 'r0' else 1))
+        shared = self.shared_libm
+        # does anybody but the owner read a wave's libm results in front of B1?  (then the owner raises its flag)
+        SEQ = 'TICK * 8u + (unsigned)stage + 1u'
         out = []
         P = out.append
         P('/* GENERATED by tools/dag/codegen_team.py from gen/citation_%s.inc -- do not edit.' % V)
@@ -191,8 +260,9 @@ class TeamGen(codegen.Gen):
             body = []
             B = body.append
             emitted = set()
-            self.libm_slot = {}
+            self.libm_slot = dict(self.libm_slot_all) if shared else {}
             self.in_override = {}
+            waited, after_b1 = set(), [False]
             done_rounds = set()
             if b == 0:
                 TM = lambda k: 'CITW_T(%d)' % k
@@ -211,6 +281,13 @@ class TeamGen(codegen.Gen):
                     if done:
                         emitted.add(m)
                         t = g.nodes[m]
+                        if m in shared:
+                            q, sl = self.row_slot[m]
+                            if q != b and q not in waited and not after_b1[0]:
+                                B('  citw_flag_wait(%d, %s);   /* libm results of wave %d */' % (q, SEQ, q))
+                                waited.add(q)
+                            B('  const double v%d = g_m[%d][%d];' % (m, q, sl))
+                            continue
                         if t[0] in LOOKUPS:
                             assert self.outslot[m][0] in done_rounds, 'look-up result used before its round'
                         if t[0] in ('sc_sin', 'sc_cos') and m not in self.libm_slot:
@@ -222,7 +299,7 @@ class TeamGen(codegen.Gen):
                         if s:
                             B(s)
                         continue
-                    if allowed is not None and g.nodes[m][0] not in LEAF:
+                    if allowed is not None and g.nodes[m][0] not in LEAF and m not in shared:
                         assert m in allowed, 'wave %d would compute node %d %s outside its share' % (b, m, g.nodes[m][:1])
                     stack.append((m, True))
                     if g.nodes[m][0] in LOOKUPS or m in self.libm_slot:
@@ -230,6 +307,44 @@ class TeamGen(codegen.Gen):
                     for c in build_dag.children(g, m):
                         if c not in emitted:
                             stack.append((c, False))
+
+            def libm_phase_shared(only=None, raise_flag=True):
+                calls = [j for j in self.calls_of.get(b, []) if j not in made and (only is None or j in only)]
+                if not calls:
+                    return
+                assert len(self.calls_of[b]) <= 16
+                B('  /* ---- libm calls this wave makes for the team: one lane per call, results in g_m[%d] */' % b)
+                for j in calls:
+                    emit_node(self.libm_calls[j][0][1])
+                B('  if (lane == 0) {')
+                for j in calls:
+                    B('    g_m[%d][%d] = %s;' % (b, 48 + self.calls_of[b].index(j), self.ref(self.libm_calls[j][0][1])))
+                B('  }')
+                B('  {')
+                lo = self.calls_of[b].index(calls[0])
+                assert [self.calls_of[b].index(j) for j in calls] == list(range(lo, lo + len(calls)))
+                B('    const int l_ = lane - %d;' % lo)
+                B('    const double a_ = g_m[%d][48 + (lane >= %d && lane < %d ? lane : %d)];' % (b, lo, lo + len(calls), lo))
+                B('    double r0_ = 0.0, r1_ = 0.0;')
+                i, first = 0, True
+                while i < len(calls):
+                    (fn, arg, prm) = self.libm_calls[calls[i]][0]
+                    k = i
+                    while k < len(calls) and self.libm_calls[calls[k]][0][0] == fn and (fn != 'pow' or self.libm_calls[calls[k]][0][2] == prm):
+                        k += 1
+                    cond = '(l_ >= %d && l_ < %d)' % (i, k) if k - i > 1 else '(l_ == %d)' % i
+                    call = {'sincos': 'sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = pow(a_, %s)' % hexf(prm)}.get(fn, 'r0_ = %s(a_)' % fn)
+                    B('    %sif %s { %s; }' % ('' if first else 'else ', cond, call))
+                    first = False
+                    i = k
+                B('    if (l_ >= 0 && l_ < %d) { g_m[%d][2 * lane] = r0_; g_m[%d][2 * lane + 1] = r1_; }' % (len(calls), b, b))
+                B('  }')
+                made.update(calls)
+                if raise_flag:
+                    B('  citw_flag_raise(%d, %s);' % (b, SEQ))
+                    B('  __builtin_amdgcn_sched_barrier(0);     /* nothing of what follows may be scheduled in front of the hand-over */')
+
+            made = set()
 
             def libm_phase(needed):
                 lst, slot = self.libm_plan(needed)
@@ -241,10 +356,10 @@ class TeamGen(codegen.Gen):
                 self.libm_slot = slot
                 B('  if (lane == 0) {')
                 for j, ((fn, arg, prm), outs) in enumerate(lst):
-                    B('    g_in[wv][%d] = %s;' % (j, self.ref(arg)))
+                    B('    g_m[wv][%d] = %s;' % (48 + j, self.ref(arg)))
                 B('  }')
                 B('  {')
-                B('    const double a_ = g_in[wv][lane < %d ? lane : 0];' % len(lst))
+                B('    const double a_ = g_m[wv][48 + (lane < %d ? lane : 0)];' % len(lst))
                 B('    double r0_ = 0.0, r1_ = 0.0;')
                 j, first = 0, True
                 while j < len(lst):
@@ -273,14 +388,20 @@ class TeamGen(codegen.Gen):
 
             def lookup_round(r, R, allowed):
                 B('  /* ---- look-up round %d */' % (r + 1))
-                for n in R['ins']:
+                mine = [(k, n) for k, n in enumerate(R['ins']) if r > 0 or self.in_owner[n] == 0]
+                for k, n in mine:
                     emit_node(n, allowed)
                 B('  if (lane == 0) {')
-                for k, n in enumerate(R['ins']):
+                for k, n in mine:
                     B('    g_in[wv][%d] = %s;' % (k, self.ref(n)))
                 B('  }')
                 if r == 0:
                     B('  %s;' % TM(5))
+                    if self.P is not None:
+                        if self.P not in waited:
+                            B('  citw_flag_wait(%d, %s);   /* the input(s) wave %d computes are in g_in[0] */' % (self.P, SEQ, self.P))
+                            waited.add(self.P)
+                        B('  %s;' % TM(9))
                 B('  citw_search<%d>(wv, S[%d], lane);' % (R['maxn'], r))
                 if r == 0:
                     B('  %s;' % TM(6))
@@ -323,13 +444,33 @@ class TeamGen(codegen.Gen):
                 for n in self.inv_frontier:
                     B(self.inv_load(n))
                     emitted.add(n)
-            libm_phase(self.have[b])
+            if b == self.P:
+                B('  /* ---- first of all: the look-up input(s) wave 0 waits for (libm pow chain of the air data) */')
+                if shared:
+                    libm_phase_shared(only=set(j for j in self.calls_of.get(b, []) if any(nd in self.handed for nd in self.libm_calls[j][1].values())), raise_flag=False)
+                else:
+                    libm_phase(self.handed)
+                for k, n in enumerate(self.rounds[0]['ins']):
+                    if self.in_owner[n] == b:
+                        emit_node(n, self.have[b])
+                B('  if (lane == 0) {')
+                for k, n in enumerate(self.rounds[0]['ins']):
+                    if self.in_owner[n] == b:
+                        B('    g_in[0][%d] = %s;' % (k, self.ref(n)))
+                B('  }')
+                B('  citw_flag_raise(%d, %s);' % (b, SEQ))
+                B('  __builtin_amdgcn_sched_barrier(0);     /* nothing of what follows may be scheduled in front of the hand-over */')
+            if shared:
+                libm_phase_shared()
+            else:
+                libm_phase(self.have[b])
             B('  %s;' % TM(4))
             if b == 0:
-                lookup_round(0, self.rounds[0], self.A0)
+                lookup_round(0, self.rounds[0], None)
                 done_rounds.add(0)
             B('  /* ---- share of this wave in the look-up independent glue */')
-            for n in self.pre_sinks[b]:
+            foreign = lambda n: any(m in shared and self.row_slot[m][0] != b for m in self.closure([n], self.S0))
+            for n in sorted(self.pre_sinks[b], key=lambda n: (foreign(n), self.pre_sinks[b].index(n))) if shared else self.pre_sinks[b]:
                 emit_node(n, self.have[b])
             for n in self.exp[b]:
                 emit_node(n, self.have[b])
@@ -351,6 +492,7 @@ class TeamGen(codegen.Gen):
                 B('  }')
             B('  %s;' % TM(0))
             B('  __syncthreads();   /* B1: look-up results (g_out0) and exchanged values (g_x) are visible to every wave */')
+            after_b1[0] = True
             B('  %s;' % TM(1))
             done_rounds.add(0)
             for n in self.imp[b]:
