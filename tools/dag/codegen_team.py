@@ -31,6 +31,9 @@ TEAM_WAVES = int(os.environ.get('CITW_TEAM_WAVES', 4))
 LOOKUP_PHASES = int(os.environ.get('CITW_TEAM_LOOKUP_COST', 1400))
 POST_ROUND2_COST = int(os.environ.get('CITW_TEAM_ROUND2_COST', 300))
 IMPORT_COST = float(os.environ.get('CITW_TEAM_IMPORT_COST', 0.0))         # units per value a wave fetches from LDS behind B1
+# initial load per wave behind B1.  Measured (profiles/r01_i_phase_profile.md): the last wave -- the one that hands the pow chain
+# over -- needs 22.7 k cycles behind B1 for 158 nodes where the others need 12-14 k for 107-134: bias it by 100 units
+POST_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_POST_BIAS', '0,0,0,100').split(',') if v]
 AFFINITY_POST = float(os.environ.get('CITW_TEAM_AFFINITY_POST', 0.0))
 SHARE_LIBM = int(os.environ.get('CITW_TEAM_SHARE_LIBM', 1))           # 1: every libm call is made by one wave, the others read the result (flag hand-over)
 SPLIT_IN = int(os.environ.get('CITW_TEAM_SPLIT_INPUTS', 1))           # 1: the heaviest round-1 input cone (pow chain) runs on a helper, handed over by flag
@@ -164,6 +167,8 @@ class TeamGen(codegen.Gen):
         phave = [set() for _ in range(K)]
         pins = [set() for _ in range(K)]          # what a wave fetches from LDS behind B1: look-up results, values of other waves
         pload = [POST_ROUND2_COST if self.nrounds > 1 else 0] + [0] * (K - 1)
+        for q, v in enumerate(POST_BIAS[:K]):
+            pload[q] += v
         powner = {}
         fetched = lambda cone: set(c for m in cone for c in build_dag.children(g, m) if c not in post and g.nodes[c][0] not in LEAF)
 
