@@ -103,7 +103,7 @@ typedef struct serl_rollout_desc {
                                        of a process starts at tick0 = steps simulated so far (incl. one per reset) */
   double t_max;                     /* 80 (eval) / 20 (train) seconds */
   int32_t max_steps;                /* rows in ref / trace buffers; 8001 for t_max = 80 */
-  int32_t lanes_per_wave;           /* 0 = auto: wave-cooperative kernels -- two wavefronts per episode while every
+  int32_t lanes_per_wave;           /* 0 = auto: wave-cooperative kernels -- four wavefronts per episode while every
                                        episode can have a CU of its own (episodes <= CUs), one wavefront per
                                        episode beyond; 1..64 = lane-per-episode kernels with that many episodes
                                        per wavefront (nominal / ice code variants only) */
