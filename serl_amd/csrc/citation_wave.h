@@ -90,7 +90,9 @@ static __device__ __forceinline__ void citw_flag_raise(int q, unsigned seq)
 }
 static __device__ __forceinline__ void citw_flag_wait(int q, unsigned seq)
 {
-  while (__hip_atomic_load(&g_flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(1);
+  // "reached", not "equal": a producer can never be an evaluation ahead (barrier B2 separates evaluations), but a poll that
+  // tolerates it cannot hang either
+  while ((int)(__hip_atomic_load(&g_flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) __builtin_amdgcn_s_sleep(1);
 }
 
 static __device__ __forceinline__ unsigned long long citw_d2u(double d) { return (unsigned long long)__double_as_longlong(d); }
