@@ -2,7 +2,7 @@
 signal B, on the states the ODE5 stages actually visit along a golden command sequence (build tooling)."""
 import sys, os, math, ctypes
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tools', 'dag'))
 import interp, build_dag, symex
 sys.path.insert(0, build_dag.ROOT)
 from oracle import dynamics

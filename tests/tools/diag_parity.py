@@ -2,7 +2,7 @@
 """GPU-vs-oracle divergence diagnosis on the BASELINE pop=50 workload (run on the GPU box)."""
 import os, sys, json
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import serl_amd
 from serl_amd import refsignals
 from oracle import rollout as R
