@@ -67,7 +67,13 @@ typedef struct serl_fault_row {
 } serl_fault_row;
 
 typedef struct serl_rollout_desc {
-  /* -- actor network (base/core/genetic_agent.py:69-102): Linear(S,H) act, L x [Linear(H,H)
+  /* -- actor network (base/core/genetic_agent.py:69-102).  f32 arithmetic, part of this ABI (the HIP kernels and the CPU
+   *    oracle implement it bit for bit): a dot product is four interleaved partial sums p[j & 3] = fmaf(w[j], h[j],
+   *    p[j & 3]) over ascending j, then bias + ((p0 + p1) + (p2 + p3)); a LayerNorm sum is a balanced pairwise tree per
+   *    block of 16 consecutive rows (zero padded), the blocks added in order; mean = sum / H, std = sqrtf(sum((x-mean)^2)
+   *    / (H - 1)), y = gamma * (x - mean) / (std + 1e-6f) + beta; tanh / ELU through det_tanhf / det_expm1f_neg
+   *    (f64 + - x / only, rounded to f32 once).
+   *    Linear(S,H) act, L x [Linear(H,H)
    *    LayerNorm(H) act], Linear(H,A) tanh.  weights: f32 [n_members][param_count], packed in
    *    state_dict order: W0[H][S] b0[H]  { Wl[H][H] bl[H] gamma_l[H] beta_l[H] } x L  Wo[A][H] bo[A] */
   int32_t state_dim, action_dim, hidden, num_layers, activation;

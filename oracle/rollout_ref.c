@@ -97,42 +97,57 @@ static float act_f(float v, int act)
   }
 }
 
-/* Actor forward, f32 (genetic_agent.py:69-109).  hbuf: 2*H scratch floats. */
+/* Actor forward, f32 (genetic_agent.py:69-109).  hbuf: 3*H scratch floats. */
+/* The f32 arithmetic of the actor as include/serl_amd.h specifies it (shared with the HIP kernels, bit for bit):
+ *   dot product   four interleaved partial sums p[j & 3] = fmaf(w[j], h[j], p[j & 3]) over ascending j (exact products,
+ *                 one rounding per step), then  bias + ((p0 + p1) + (p2 + p3))
+ *   LayerNorm sum balanced pairwise tree over blocks of 16 consecutive rows (zero padded), the blocks added in order
+ * Any fixed order is as faithful to the reference as any other (torch's CPU kernels use vector lanes and FMA); this one
+ * has short dependency chains on a 64-lane wavefront and on a CPU alike. */
+static float dot4(const float *w, const float *h, int n, float bias)
+{
+  float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int j = 0; j < n; ++j) p[j & 3] = fmaf(w[j], h[j], p[j & 3]);
+  return bias + ((p[0] + p[1]) + (p[2] + p[3]));
+}
+
+static float tree16(const float *x, int n)        /* n <= 16 values, zero padded */
+{
+  float t[16];
+  for (int i = 0; i < 16; ++i) t[i] = i < n ? x[i] : 0.0f;
+  for (int s = 1; s < 16; s <<= 1)
+    for (int i = 0; i < 16; i += 2 * s) t[i] = t[i] + t[i + s];
+  return t[0];
+}
+
+static float tree_sum(const float *x, int n)
+{
+  float s = tree16(x, n < 16 ? n : 16);
+  for (int b = 16; b < n; b += 16) s = s + tree16(x + b, n - b < 16 ? n - b : 16);
+  return s;
+}
+
 static void actor_forward(const serl_rollout_desc *d, const float *w, const float *obs, float *act_out,
                           float *hbuf)
 {
   const int S = d->state_dim, H = d->hidden, A = d->action_dim, L = d->num_layers;
-  float *h0 = hbuf, *h1 = hbuf + H;
+  float *h0 = hbuf, *h1 = hbuf + H, *h2 = hbuf + 2 * H;
   const float *W = w, *b = w + (size_t)H * S;
-  for (int i = 0; i < H; ++i) {
-    float acc = b[i];
-    for (int j = 0; j < S; ++j) acc = acc + W[i * S + j] * obs[j];
-    h0[i] = act_f(acc, d->activation);
-  }
+  for (int i = 0; i < H; ++i) h0[i] = act_f(dot4(W + (size_t)i * S, obs, S, b[i]), d->activation);
   w = b + H;
   for (int l = 0; l < L; ++l) {
     const float *Wl = w, *bl = w + (size_t)H * H, *g = bl + H, *be = g + H;
-    for (int i = 0; i < H; ++i) {
-      float acc = bl[i];
-      for (int j = 0; j < H; ++j) acc = acc + Wl[i * H + j] * h0[j];
-      h1[i] = acc;
-    }
-    float mean = 0.0f;
-    for (int i = 0; i < H; ++i) mean = mean + h1[i];
-    mean = mean / (float)H;
-    float var = 0.0f;
-    for (int i = 0; i < H; ++i) { float dlt = h1[i] - mean; var = var + dlt * dlt; }
-    float std = sqrtf(var / (float)(H - 1));
-    float den = std + 1e-6f;
+    for (int i = 0; i < H; ++i) h1[i] = dot4(Wl + (size_t)i * H, h0, H, bl[i]);
+    const float mean = tree_sum(h1, H) / (float)H;
+    for (int i = 0; i < H; ++i) { const float dlt = h1[i] - mean; h2[i] = dlt * dlt; }
+    const float var = tree_sum(h2, H);
+    const float std = sqrtf(var / (float)(H - 1));
+    const float den = std + 1e-6f;
     for (int i = 0; i < H; ++i) h0[i] = act_f(g[i] * (h1[i] - mean) / den + be[i], d->activation);
     w = be + H;
   }
   const float *Wo = w, *bo = w + (size_t)A * H;
-  for (int i = 0; i < A; ++i) {
-    float acc = bo[i];
-    for (int j = 0; j < H; ++j) acc = acc + Wo[i * H + j] * h0[j];
-    act_out[i] = det_tanhf(acc);
-  }
+  for (int i = 0; i < A; ++i) act_out[i] = det_tanhf(dot4(Wo + (size_t)i * H, h0, H, bo[i]));
 }
 
 int serl_param_count(int S, int H, int L, int A) { return H * S + H + L * (H * H + 3 * H) + A * H + A; }
@@ -253,7 +268,7 @@ static void *worker(void *p)
 {
   job_t *j = (job_t *)p;
   CitInstance *I = (CitInstance *)malloc((size_t)cit_instance_size());
-  float *hbuf = (float *)malloc(sizeof(float) * 2 * (size_t)j->d->hidden);
+  float *hbuf = (float *)malloc(sizeof(float) * 3 * (size_t)j->d->hidden);
   for (int e = j->e0; e < j->e1; e += j->stride) {
     int rc = run_episode(j->d, j->bd, e, I, hbuf);
     if (rc) j->rc = rc;

