@@ -62,14 +62,17 @@ static DET_FN float det_tanhf(float xf)
   if (xf != xf) return xf;
   const double x = (double)xf;
   const double ax = x < 0.0 ? -x : x;
-  double t;
-  if (ax > 20.0) t = 1.0;
-  else {
-    long long k;
-    const double q = det_expm1_reduced(ax + ax, &k);
-    if (k == 0) t = q / (q + 2.0);
-    else t = 1.0 - 2.0 / (DET_POW2(k) * (q + 1.0) + 1.0);
-  }
+  // branch-free over the lanes of a wavefront (one division instead of one per divergent branch); per lane the operations
+  // are those of the specification:  k == 0: q / (q + 2);  else 1 - 2 / (2^k (q + 1) + 1);  |x| > 20: 1
+  const double axc = ax > 20.0 ? 20.0 : ax;
+  long long k;
+  const double q = det_expm1_reduced(axc + axc, &k);
+  const bool small = k == 0;
+  const double num = small ? q : 2.0;
+  const double den = small ? q + 2.0 : DET_POW2(k) * (q + 1.0) + 1.0;
+  const double r = num / den;
+  double t = small ? r : 1.0 - r;
+  t = ax > 20.0 ? 1.0 : t;
   return (float)(x < 0.0 ? -t : t);
 }
 
