@@ -213,6 +213,48 @@ __device__ static const double citw_ode5_B[6][6] = {
   {0.09114583333333333, 0.0, 0.44923629829290207, 0.6510416666666666, -0.322376179245283, 0.13095238095238096},
 };
 
+// ODE5 stage combination of one state component:  X_i = y_i + sum_{j <= st} f_j,i * (B[st][j] * h),  accumulated in j order
+// like the reference (rt_ertODEUpdateContinuousStates @0x9eb8..0xa4f3).  Specialised per stage: the products B[st][j] * h
+// fold to literals (the same IEEE product the run-time expression gives) and all stage derivatives are fetched from LDS
+// together, instead of a variable-length loop with a constant-memory load and an LDS round trip per term.
+static __host__ __device__ constexpr double citw_ode5_b(int st, int j)
+{
+  constexpr double B[6][6] = {
+    {0.2, 0, 0, 0, 0, 0},
+    {0.075, 0.225, 0, 0, 0, 0},
+    {0.9777777777777777, -3.7333333333333334, 3.5555555555555554, 0, 0, 0},
+    {2.9525986892242035, -11.595793324188385, 9.822892851699436, -0.2908093278463649, 0, 0},
+    {2.8462752525252526, -10.757575757575758, 8.906422717743473, 0.2784090909090909, -0.2735313036020583, 0},
+    {0.09114583333333333, 0.0, 0.44923629829290207, 0.6510416666666666, -0.322376179245283, 0.13095238095238096},
+  };
+  return B[st][j];
+}
+
+template <int ST>
+static __device__ __forceinline__ double citw_ode5_combine_st(const double (*f)[20], int li, double yi)
+{
+  constexpr double h = 0.01;
+  double fv[ST + 1];
+#pragma unroll
+  for (int j = 0; j <= ST; ++j) fv[j] = f[j][li];
+  double acc = fv[0] * (citw_ode5_b(ST, 0) * h);
+#pragma unroll
+  for (int j = 1; j <= ST; ++j) acc = acc + fv[j] * (citw_ode5_b(ST, j) * h);
+  return acc + yi;
+}
+
+static __device__ __forceinline__ double citw_ode5_combine(int st, const double (*f)[20], int li, double yi)
+{
+  switch (st) {           // wave-uniform
+    case 0: return citw_ode5_combine_st<0>(f, li, yi);
+    case 1: return citw_ode5_combine_st<1>(f, li, yi);
+    case 2: return citw_ode5_combine_st<2>(f, li, yi);
+    case 3: return citw_ode5_combine_st<3>(f, li, yi);
+    case 4: return citw_ode5_combine_st<4>(f, li, yi);
+    default: return citw_ode5_combine_st<5>(f, li, yi);
+  }
+}
+
 // Per-episode dynamics state of the wave kernel: lane i < 19 keeps continuous state i (ODE5 combination per lane);
 // the model evaluation reads all 19 as wave-uniform LDS loads from g_xs.
 struct CitwState {
