@@ -202,16 +202,7 @@ static __device__ __noinline__ double citw_table3(const double *t3, double u0, d
   return (u2 == z1) ? b : d + a;
 }
 
-// Dormand-Prince "ode5" tableau as the reference's literal pool holds it (0x13688, 0x13898..0x13938)
-__device__ static const double citw_ode5_A[6] = {0.2, 0.3, 0.8, 0.8888888888888888, 1.0, 1.0};
-__device__ static const double citw_ode5_B[6][6] = {
-  {0.2, 0, 0, 0, 0, 0},
-  {0.075, 0.225, 0, 0, 0, 0},
-  {0.9777777777777777, -3.7333333333333334, 3.5555555555555554, 0, 0, 0},
-  {2.9525986892242035, -11.595793324188385, 9.822892851699436, -0.2908093278463649, 0, 0},
-  {2.8462752525252526, -10.757575757575758, 8.906422717743473, 0.2784090909090909, -0.2735313036020583, 0},
-  {0.09114583333333333, 0.0, 0.44923629829290207, 0.6510416666666666, -0.322376179245283, 0.13095238095238096},
-};
+// Dormand-Prince "ode5" tableau as the reference's literal pool holds it (0x13688, 0x13898..0x13938): citw_ode5_a / citw_ode5_b below
 
 // ODE5 stage combination of one state component:  X_i = y_i + sum_{j <= st} f_j,i * (B[st][j] * h),  accumulated in j order
 // like the reference (rt_ertODEUpdateContinuousStates @0x9eb8..0xa4f3).  Specialised per stage: the products B[st][j] * h
@@ -228,6 +219,17 @@ static __host__ __device__ constexpr double citw_ode5_b(int st, int j)
     {0.09114583333333333, 0.0, 0.44923629829290207, 0.6510416666666666, -0.322376179245283, 0.13095238095238096},
   };
   return B[st][j];
+}
+
+// A[st] of the tableau as scalar selects of literals (no constant-memory load on the path into the next evaluation)
+static __device__ __forceinline__ double citw_ode5_a(int st)
+{
+  double a = 0.2;
+  a = st == 1 ? 0.3 : a;
+  a = st == 2 ? 0.8 : a;
+  a = st == 3 ? 0.8888888888888888 : a;
+  a = st >= 4 ? 1.0 : a;
+  return a;
 }
 
 template <int ST>
