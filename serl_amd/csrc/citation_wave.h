@@ -20,6 +20,9 @@
 #include <stdint.h>
 
 #define CITW_MAX_ROUNDS 3
+#ifndef CITW_SEARCH_BATCH
+#define CITW_SEARCH_BATCH 0     // 1 (team kernels): index-search compares in batches of eight; costs 44 VGPRs, which the one-wave kernels lack
+#endif
 #define CITW_RO_LDS_WORDS 12040
 
 struct CitwSearch { uint16_t row, n, in, pad; };                                // 8 B: row of g_bp, entries, input slot
@@ -110,6 +113,28 @@ static __device__ __forceinline__ void citw_search(const int wv, const CitwSearc
   const double u = g_in[wv][d.in];
   const double *x = g_bp[d.row];
   const int n = d.n;
+#if CITW_SEARCH_BATCH
+  int lt = 0;
+  // compares in batches of eight, then their additions: a compare result (an SGPR pair) may not be consumed by the very
+  // next VALU instruction on gfx950 -- one by one every compare drags an s_nop behind it
+  constexpr int NP = (MAXN + 1) & ~1;
+  double xv[NP];
+#pragma unroll
+  for (int i = 0; i < NP; i += 2) {
+    const v2d v = *(const v2d *)(x + i);
+    xv[i] = v.x; xv[i + 1] = v.y;
+  }
+#pragma unroll
+  for (int i0 = 0; i0 < NP; i0 += 8) {
+    bool c[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) c[q] = (i0 + q < NP) && (xv[i0 + q < NP ? i0 + q : 0] < u);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lt += c[q] ? 1 : 0;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#else
   int lt = 0;
 #pragma unroll
   for (int i = 0; i < ((MAXN + 1) & ~1); i += 2) {
@@ -117,6 +142,7 @@ static __device__ __forceinline__ void citw_search(const int wv, const CitwSearc
     lt += (v.x < u) ? 1 : 0;
     lt += (v.y < u) ? 1 : 0;
   }
+#endif
   const int le = lt + ((x[lt < CITW_BP_PAD - 1 ? lt : CITW_BP_PAD - 1] == u) ? 1 : 0);
   int idx = ((u < 0.0) ? le : lt) - 1;
   idx = idx < 0 ? 0 : idx;

@@ -1,5 +1,6 @@
-// rollout_team_gust.hip -- two-wavefront-per-episode rollout kernels for the 'gust' dynamics code variant
+// rollout_team_gust.hip -- team (four wavefronts per episode) rollout kernels for the 'gust' dynamics code variant
 // (rollout_team.inc, gen/citation_gust_team.inc): the latency-bound regime, fewer episodes than CUs.
+#define CITW_SEARCH_BATCH 1
 #include "citation_wave.h"
 #include "rollout_device.h"
 #include "gen/citation_gust_wave.inc"   // look-up descriptor tables (shared with the one-wave kernels)

@@ -1,5 +1,6 @@
-// rollout_team_nominal.hip -- two-wavefront-per-episode rollout kernels for the 'nominal' dynamics code variant
+// rollout_team_nominal.hip -- team (four wavefronts per episode) rollout kernels for the 'nominal' dynamics code variant
 // (rollout_team.inc, gen/citation_nominal_team.inc): the latency-bound regime, fewer episodes than CUs.
+#define CITW_SEARCH_BATCH 1
 #include "citation_wave.h"
 #include "rollout_device.h"
 #include "gen/citation_nominal_wave.inc"   // look-up descriptor tables (shared with the one-wave kernels)
