@@ -150,7 +150,7 @@ def main():
     # collected and corrected as MI355X_MICROARCH.md prescribes); only quoted for the configuration it was measured on
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_j_pmc_traffic.json')))
+        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_k_pmc_traffic.json')))
         if pop == 50 and ne == 3 and a.lanes == 0:
             traffic = pm['traffic_bytes_per_launch']
     except Exception:
@@ -170,7 +170,7 @@ def main():
                      'frac': ach_hbm / HBM_PEAK, 'traffic': traffic,
                      'note': 'path is instruction-issue bound on one / two wavefronts per episode, not HBM-bound (DESIGN.md): '
                              'algorithmic traffic is 48 B per env-step; achieved = steps x 48 B / kernel time; traffic = bytes '
-                             'per launch from profiles/r01_j_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE)'},
+                             'per launch from profiles/r01_k_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE)'},
         'roofline_fp64': {'bound': 'valu-f64', 'achieved': ach_f64 / 1e12, 'peak': FP64_PEAK / 1e12, 'unit': 'TFLOP/s',
                           'frac': ach_f64 / FP64_PEAK},
         't_step_us': k_ms * 1e3 / T,
