@@ -31,7 +31,7 @@ struct RolloutArgs {
 /* tanh / expm1 of the f32 actor (product code; the oracle restates the same arithmetic), evaluated in f64 with + - * / only (no libm, no FMA contraction), so that the
  * CPU oracle and the HIP kernel return bit-identical f32 activations (specified in include/serl_amd.h):
  *   z = 2|x| (tanh) or x (expm1, x <= 0);  k = round(z / ln2);  r = (z - k*LN2_HI) - k*LN2_LO;
- *   q = expm1(r) by the Taylor polynomial through r^13/13! in Horner form;
+ *   q = expm1(r) by the Taylor polynomial through r^13/13! in Estrin form (pairs, quads, octets);
  *   tanh = q/(q+2) if k == 0 else 1 - 2/(2^k (q+1) + 1);   expm1 = q if k == 0 else 2^k (q+1) - 1;
  * the f64 result (error ~1e-16) is rounded to f32 once. */
 static DET_FN double det_expm1_reduced(double z, long long *kout)
@@ -41,20 +41,16 @@ static DET_FN double det_expm1_reduced(double z, long long *kout)
   const long long k = v < 0.0 ? -(long long)(0.5 - v) : (long long)(v + 0.5);
   const double kd = (double)k;
   const double r = (z - kd * LN2_HI) - kd * LN2_LO;
-  double p = 1.6059043836821613e-10;            /* 1/13! */
-  p = p * r + 2.08767569878681e-09;             /* 1/12! */
-  p = p * r + 2.505210838544172e-08;            /* 1/11! */
-  p = p * r + 2.755731922398589e-07;            /* 1/10! */
-  p = p * r + 2.7557319223985893e-06;           /* 1/9! */
-  p = p * r + 2.48015873015873e-05;             /* 1/8! */
-  p = p * r + 0.0001984126984126984;            /* 1/7! */
-  p = p * r + 0.001388888888888889;             /* 1/6! */
-  p = p * r + 0.008333333333333333;             /* 1/5! */
-  p = p * r + 0.041666666666666664;             /* 1/4! */
-  p = p * r + 0.16666666666666666;              /* 1/3! */
-  p = p * r + 0.5;                              /* 1/2! */
+  /* expm1(r) - r = r^2 P(r), P of degree 11 with the Taylor coefficients 1/2! .. 1/13!, in Estrin form (dependency depth
+   * 7 instead of 24: a lone GPU wavefront waits out every dependent operation) */
+  const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+  const double b0 = 0.5 + 0.16666666666666666 * r, b1 = 0.041666666666666664 + 0.008333333333333333 * r;
+  const double b2 = 0.001388888888888889 + 0.0001984126984126984 * r, b3 = 2.48015873015873e-05 + 2.7557319223985893e-06 * r;
+  const double b4 = 2.755731922398589e-07 + 2.505210838544172e-08 * r, b5 = 2.08767569878681e-09 + 1.6059043836821613e-10 * r;
+  const double c0 = b0 + b1 * r2, c1 = b2 + b3 * r2, c2 = b4 + b5 * r2;
+  const double p = (c0 + c1 * r4) + c2 * r8;
   *kout = k;
-  return r + (r * r) * p;
+  return r + r2 * p;
 }
 
 static DET_FN float det_tanhf(float xf)
