@@ -219,3 +219,93 @@ def test_sensor_noise_wrappers_vs_reference_python(golden, mode):
     m = R.rollout(w, NET['serl50'], [0, 1, 2], ref, build=build, sensor_noise=sn[[1]], sensor_row=[-1, 0, -1], tick0=tick0,
                   t_max=80, threads=3)
     assert m['fitness'][0] == clean['fitness'][0] and m['fitness'][1] == o['fitness'][1] and m['fitness'][2] == clean['fitness'][2]
+
+
+def _np_actor(w, net, obs):
+    """The actor's f32 arithmetic as include/serl_amd.h specifies it, restated with numpy scalars: dot products as four
+    interleaved fma partial sums, LayerNorm sums as pairwise trees per 16 rows, tanh through the f64 det_tanhf."""
+    import math
+    f32 = np.float32
+    S, H, L, A = net['state_dim'], net['hidden'], net['num_layers'], net['action_dim']
+
+    def fma(a, b, c):            # exact product + one rounding: f32 operands are exact in f64 and the product fits 48 bits
+        return f32(np.float64(a) * np.float64(b) + np.float64(c))
+
+    def dot4(wr, h, bias):
+        p = [f32(0)] * 4
+        for j in range(len(h)):
+            p[j & 3] = fma(wr[j], h[j], p[j & 3])
+        return f32(bias + f32(f32(p[0] + p[1]) + f32(p[2] + p[3])))
+
+    def tree16(x):
+        t = [f32(v) for v in x] + [f32(0)] * (16 - len(x))
+        s = 1
+        while s < 16:
+            for i in range(0, 16, 2 * s):
+                t[i] = f32(t[i] + t[i + s])
+            s *= 2
+        return t[0]
+
+    def tree_sum(x):
+        s = tree16(x[:16])
+        for b in range(16, len(x), 16):
+            s = f32(s + tree16(x[b:b + 16]))
+        return s
+
+    def det_tanhf(xf):
+        x = float(xf); ax = abs(x)
+        if ax > 20.0:
+            t = 1.0
+        else:
+            z = ax + ax
+            v = z * 1.4426950408889634
+            k = int(v + 0.5)
+            r = (z - k * 0.6931471803691238) - k * 1.9082149292705877e-10
+            r2 = r * r; r4 = r2 * r2; r8 = r4 * r4
+            b = [0.5 + 0.16666666666666666 * r, 0.041666666666666664 + 0.008333333333333333 * r,
+                 0.001388888888888889 + 0.0001984126984126984 * r, 2.48015873015873e-05 + 2.7557319223985893e-06 * r,
+                 2.755731922398589e-07 + 2.505210838544172e-08 * r, 2.08767569878681e-09 + 1.6059043836821613e-10 * r]
+            c = [b[0] + b[1] * r2, b[2] + b[3] * r2, b[4] + b[5] * r2]
+            q = r + r2 * ((c[0] + c[1] * r4) + c[2] * r8)
+            t = q / (q + 2.0) if k == 0 else 1.0 - 2.0 / (math.ldexp(1.0, k) * (q + 1.0) + 1.0)
+        return f32(-t if x < 0 else t)
+    assert net['activation'] == 'tanh'
+    o = 0
+    W0 = w[o:o + H * S].reshape(H, S); o += H * S
+    b0 = w[o:o + H]; o += H
+    h = [det_tanhf(dot4(W0[i], obs, b0[i])) for i in range(H)]
+    for _ in range(L):
+        W = w[o:o + H * H].reshape(H, H); o += H * H
+        bl, g, be = w[o:o + H], w[o + H:o + 2 * H], w[o + 2 * H:o + 3 * H]; o += 3 * H
+        y = [dot4(W[i], h, bl[i]) for i in range(H)]
+        mean = f32(tree_sum(y) / f32(H))
+        d = [f32(v - mean) for v in y]
+        var = tree_sum([f32(v * v) for v in d])
+        den = f32(np.sqrt(f32(var / f32(H - 1))) + f32(1e-6))
+        h = [det_tanhf(f32(f32(f32(g[i] * d[i]) / den) + be[i])) for i in range(H)]
+    Wo = w[o:o + A * H].reshape(A, H); o += A * H
+    bo = w[o:o + A]
+    return np.array([det_tanhf(dot4(Wo[i], h, bo[i])) for i in range(A)], dtype=np.float32)
+
+
+@pytest.mark.parametrize('tag', ['serl50', 'serl10'])
+def test_actor_arithmetic_is_the_specified_one(golden, tag):
+    """First action of an episode (obs0 = carried error, initial p q r alpha) against the numpy restatement of the
+    arithmetic the C ABI specifies -- bit for bit."""
+    from oracle import rollout as R
+    from serl_amd import builds, refsignals
+    net = NET[tag]
+    if net['activation'] != 'tanh':
+        pytest.skip('restatement covers tanh')
+    w = golden('actors')[tag][[0, 1, 2]]
+    ref = refsignals.tabulate(*refsignals.base_reference(20), 20)
+    rng = np.random.default_rng(5)
+    err0 = rng.normal(0, 0.05, (3, 3))
+    o = R.rollout(w, net, [0, 1, 2], ref, err0=err0, t_max=20, traces=True)
+    x0 = builds.load('h2000_v90')[0]['x0']
+    bound = 10.0 * (3.14159265358979323846 / 180.0)
+    for e in range(3):
+        obs = np.array([err0[e, 0], err0[e, 1], err0[e, 2], x0[0], x0[1], x0[2], x0[4]], dtype=np.float64).astype(np.float32)
+        a = _np_actor(w[e], net, obs)
+        u = [-bound + float(np.float32(0.5) * (a[i] + np.float32(1.0))) * (bound - (-bound)) for i in range(3)]
+        np.testing.assert_array_equal(o['actions'][e][0], np.array(u))
