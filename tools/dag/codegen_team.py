@@ -5,18 +5,27 @@ With one wavefront per SIMD every instruction -- VALU, SALU, LDS, waitcnt -- cos
 evaluation (~4 500 instructions) is issue-bound on a single wavefront.  When there are fewer episodes than CUs, the
 other SIMDs of the CU take a share of the work: a team of K wavefronts (K = 4 by default: one per SIMD of the CU) per episode.
 
-  wave 0 (main)     the serial chain: libm calls + glue that the round-1 look-up inputs need -> index search, 2-D and
-                    1-D interpolation passes -> [barrier B1] -> later look-up rounds, its share of the derivative cones
-                    -> [barrier B2]
-  waves 1..K-1      their own libm calls (sincos of the attitude angles ...) + a share of the glue that does NOT depend
-  (helpers)         on any look-up (rotation matrices, gravity, engines, kinematic equations ...) -> [B1] -> a share of
-                    the derivative cones behind the round-1 look-ups (results are in LDS for everybody), Derivative-
-                    block banks -> [B2]
+  wave 0 (main)     cones of the round-1 look-up inputs (all but the one behind the libm pow chain) -> [poll the flag of the
+                    wave that hands that input over] -> index search, 2-D and 1-D interpolation passes -> [barrier B1]
+                    -> later look-up rounds, its share of the derivative cones -> [barrier B2]
+  waves 1..K-1      the libm calls of the evaluation, each made by exactly ONE wave (lane-parallel), results in its g_m row,
+  (helpers)         published by an LDS flag (release store of the evaluation's sequence number; a consumer polls it
+                    once -- acquire -- before its first read); the last wave starts with the pow / exp chain of the air
+                    data and puts the look-up input behind it into wave 0's input row; then a share of the glue that does
+                    NOT depend on any look-up (rotation matrices, gravity, engines, kinematic equations ...) -> [B1] -> a
+                    share of the derivative cones behind the round-1 look-ups (results are in LDS for everybody),
+                    Derivative-block banks -> [B2]
 
-Every sink (a value needed later, with its cone of ancestors) goes to the wave that ends up with the smallest load;
-light sub-expressions shared by several cones are recomputed rather than exchanged; what a wave needs from another
-one's pre-barrier values crosses through LDS (g_x) around B1.  Every wave executes exactly two workgroup barriers per
-evaluation.  The arithmetic (operation order per value) is that of the single-wave code: results are bit-identical.
+Every sink (a value needed later, with its cone of ancestors) goes to the wave that minimises load + AFFINITY x the nodes
+it would have to add (it leans towards the wave that already holds most of the cone); libm results are imports for
+everybody but their maker, light sub-expressions shared by several cones are recomputed rather than exchanged; what a wave
+needs from another one's pre-barrier values crosses through LDS (g_x) around B1.  Every wave executes exactly two workgroup
+barriers per evaluation; only consumers ever wait on a flag, and only if the producer is late.  The arithmetic (operation
+order per value) is that of the single-wave code: results are bit-identical.
+
+Knobs (environment, for sweeps; defaults are the measured best): CITW_TEAM_WAVES, CITW_TEAM_LOOKUP_COST,
+CITW_TEAM_ROUND2_COST, CITW_TEAM_AFFINITY, CITW_TEAM_SHARE_LIBM, CITW_TEAM_SPLIT_INPUTS, CITW_TEAM_FN_SCALE,
+CITW_TEAM_LIBM_SCALE, CITW_TEAM_POST_BIAS, CITW_TEAM_IMPORT_COST, CITW_TEAM_AFFINITY_POST.
 
 Usage: python tools/dag/codegen_team.py [variant ...]      (CITW_TEAM_WAVES=2|3|4 overrides the team size)
 """
