@@ -34,7 +34,9 @@ static __device__ __noinline__ void CIT_STEP(CitCtx *gc, const double *cmd_in, d
       lc.t = (s == 5) ? lc.stop_time : (s == 1 ? hB[0] + t0 : h * cit_ode5_A[s - 1] + t0);
     }
     lc.major = (s == 0) ? 1 : 0;
+#ifndef CIT_NO_AXES
     cit_axes_prepare(&lc.ax, lc.X[4], lc.X[5], lc.X[6], lc.X[7], lc.X[8]);
+#endif
     CIT_MODEL(&lc, cmd, out);   // s == 0: stop_time = (tick+1)*dt; rtY latch; Derivative-block banks
     CIT_DERIV(&lc, f[s]);
   }

@@ -60,3 +60,11 @@ def test_generated_team_sources_are_current(variant):
     text = codegen_team.TeamGen(variant).emit_team()
     have = open(os.path.join(ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_team.inc' % variant)).read()
     assert text == have, 'serl_amd/csrc/gen/citation_%s_team.inc is stale: run python tools/dag/codegen_team.py' % variant
+
+
+@pytest.mark.parametrize('variant', ['nominal', 'ice'])
+def test_generated_lane_sources_are_current(variant):
+    import codegen_lane
+    text = codegen_lane.LaneGen(variant).emit_lane()
+    have = open(os.path.join(ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_lane.inc' % variant)).read()
+    assert text == have, 'serl_amd/csrc/gen/citation_%s_lane.inc is stale: run python tools/dag/codegen_lane.py nominal ice' % variant
