@@ -110,3 +110,30 @@ def test_batched_reference_tabulation_matches_the_host_tables():
                                    refsignals.SmoothedStepSequence(tt[e], a_ph[e], 8), 80)
         np.testing.assert_allclose(got[e], want, rtol=0, atol=1e-15)
     assert got.shape == (4, 8001, 3) and got[0, -1, 0] != got[0, -2, 0]     # the trim drops out at the terminal sample
+
+
+def test_store_transitions_follows_agent_evaluate():
+    """base/core/agent.py:101-125: every stored step goes to the shared buffer and the agent's own buffer, cost-flagged
+    steps also to its critical buffer; num_frames / gen_frames advance per step, num_episodes per stored episode."""
+    from serl_amd.generation import store_transitions
+
+    class Buf(list):
+        def add(self, *t):
+            self.append(t)
+
+    class Agent:
+        def __init__(self):
+            self.buffer, self.critical_buffer = Buf(), Buf()
+    rng = np.random.default_rng(0)
+    rows = rng.normal(size=(5, 20)).astype(np.float32)
+    rows[:, 18] = [0, 0, 0, 0, 1]          # done
+    rows[:, 19] = [0, 1, 0, 1, 0]          # cost
+    shared, ag, counters = Buf(), Agent(), {'num_frames': 10, 'num_episodes': 2}
+    store_transitions(rows, ag, shared, counters)
+    assert len(shared) == 5 and len(ag.buffer) == 5 and len(ag.critical_buffer) == 2
+    s, a, ns, r, d = shared[4]
+    assert s.dtype == np.float64 and s.shape == (7,) and a.shape == (3,) and ns.shape == (7,) and d == 1.0
+    np.testing.assert_array_equal(s, rows[4, 0:7].astype(np.float64))
+    np.testing.assert_array_equal(ag.critical_buffer[1][1], rows[3, 7:10])
+    assert counters == {'num_frames': 15, 'gen_frames': 5, 'num_episodes': 3}
+    store_transitions(rows[:2], Agent(), None, None)      # no shared buffer, no counters: still fine
