@@ -168,7 +168,7 @@ def main():
         'kernel_ms': k_ms,
         'roofline': {'bound': 'hbm', 'achieved': ach_hbm / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                      'frac': ach_hbm / HBM_PEAK, 'traffic': traffic,
-                     'note': 'path is instruction-issue bound on one / two wavefronts per episode, not HBM-bound (DESIGN.md): '
+                     'note': 'path is instruction-issue / dependent-latency bound on four wavefronts per episode, not HBM-bound (DESIGN.md): '
                              'algorithmic traffic is 48 B per env-step; achieved = steps x 48 B / kernel time; traffic = bytes '
                              'per launch from profiles/r01_k_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE)'},
         'roofline_fp64': {'bound': 'valu-f64', 'achieved': ach_f64 / 1e12, 'peak': FP64_PEAK / 1e12, 'unit': 'TFLOP/s',
