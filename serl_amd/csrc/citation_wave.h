@@ -46,7 +46,7 @@ __shared__ double g_xs[CITW_MAX_WAVES][20];       // continuous states X[19] of 
 __shared__ double g_cmd[CITW_MAX_WAVES][12];      // command vector of the current env step
 __shared__ double g_act[CITW_MAX_WAVES][16][3];   // action trace of the last <= 16 env steps (flushed as one coalesced store)
 __shared__ double g_inv[CITW_MAX_WAVES][128];     // per-step invariants of the model (citw_<v>_step_invariants)
-__shared__ double g_x[256];                       // team kernels: values wave 1 computes for wave 0 (rollout_team.inc)
+__shared__ double g_x[256];                       // team kernels: values that cross between the wavefronts at barrier B1
 
 #define CITW_MAX_CONSTS 192
 __shared__ double g_k[CITW_MAX_CONSTS];           // f64 literals of the model (only when generated with --lds-consts)
