@@ -137,3 +137,17 @@ def test_store_transitions_follows_agent_evaluate():
     np.testing.assert_array_equal(ag.critical_buffer[1][1], rows[3, 7:10])
     assert counters == {'num_frames': 15, 'gen_frames': 5, 'num_episodes': 3}
     store_transitions(rows[:2], Agent(), None, None)      # no shared buffer, no counters: still fine
+
+
+def test_sensor_noise_table_draw_order():
+    """envs/noise/citation.py:71-82 draws randn(3), randn(1), randn(1), randn(2) per step() from the legacy generator; one
+    randn(n, 7) block of the same generator must yield the same stream (the Box-Muller cache lives in the generator)."""
+    from serl_amd import builds
+    rs = np.random.RandomState(42)
+    rows = []
+    for _ in range(6):
+        a, b, c, d = rs.randn(3), rs.randn(1), rs.randn(1), rs.randn(2)
+        rows.append(np.concatenate([3.0 * 10**(-5) + 6.3 * 10**(-4) * a, 4.0 * 10**(-10) * b,
+                                    1.8 * 10**(-3) + 2.7 * 10**(-4) * c, 4.0 * 10**(-3) + 3.2 * 10**(-5) * d]))
+    np.testing.assert_array_equal(builds.sensor_noise_table(5, np.random.RandomState(42)), np.array(rows))
+    assert builds.has_sensor_noise('PHlab_attitude_noise') and builds.has_sensor_noise('gust') and not builds.has_sensor_noise('ice')
