@@ -11,9 +11,10 @@
  *   envs/phlabenv.py:347-399         calc_error / get_reward / get_cost / check_bounds
  *   envs/phlabenv.py:401-482         reset / step
  *   envs/{be,jr,sa,se}/citation.py:71-79   actuator faults seen by the plant only
- * Float-32 arithmetic of the actor is sequential (acc = bias; acc += w*x in index order, no FMA);
- * torch's CPU kernels use a different (BLAS) order -- agreement is to f32 rounding, see
- * tests/test_actor_parity.py.
+ * Float-32 arithmetic of the actor: the fixed order include/serl_amd.h specifies (four interleaved fma partial
+ * sums per dot product, pairwise LayerNorm trees; dot4 / tree_sum below), shared bit for bit with the HIP kernels.
+ * torch's CPU kernels use another (vectorised) order -- agreement with the reference is to f32 rounding, measured
+ * per shipped actor in tests/golden/make_sensitivity.py and asserted in tests/test_oracle_rollout.py.
  */
 #define _GNU_SOURCE
 #include <math.h>
@@ -210,6 +211,7 @@ static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, in
       for (int i = 0; i < 3; ++i) {
         double an = clipd((double)a[i] + noise[(size_t)k * 3 + i], -1.0, 1.0);
         u[i] = low + 0.5 * (an + 1.0) * (high - low);
+        a[i] = (float)an;                              /* agent.py:93,103: the transition holds the executed action */
       }
     } else {
       for (int i = 0; i < 3; ++i) {

@@ -310,3 +310,54 @@ def test_actor_arithmetic_is_the_specified_one(golden, tag):
         a = _np_actor(w[e], net, obs)
         u = [-bound + float(np.float32(0.5) * (a[i] + np.float32(1.0))) * (bound - (-bound)) for i in range(3)]
         np.testing.assert_array_equal(o['actions'][e][0], np.array(u))
+
+
+NOISE_SD, NOISE_CLIP = 0.2962183114680794, 0.5      # base/parameters.py:49,76
+NOISE_CASES = [('serl50_18_n', 'serl50', 18, 20, True), ('td3_0_n', 'td3', 0, 20, True),
+               ('serl50_7_n80', 'serl50', 7, 80, True), ('serl50_0_clean', 'serl50', 0, 20, False)]
+
+
+def noise_case_inputs(golden, name, tag, idx, t_max, noisy):
+    """(weights, reference table, pre-drawn clipped noise table) of one tests/golden/make_noise_golden.py case: the
+    reference draws `noise_sd * np.random.randn(3)` once per step (agent.py:91) -- the same legacy stream in one block."""
+    from oracle import signals as S
+    g = golden('noise_path')
+    T = int(g[name + '_ret'][2])
+    tt = np.linspace(0., t_max, 6)
+    ref = S.tabulate_refs(S.SmoothedStepSequence(tt, [0, 12, 3, -4, -8, 2], smooth_width=t_max // 10),
+                          S.SmoothedStepSequence(tt, [2, -2, 2, 10, 2, -6], smooth_width=t_max // 10), t_max)
+    noise = None
+    if noisy:
+        noise = np.clip(NOISE_SD * np.random.RandomState(int(g[name + '_seed'])).randn(T, 3), -NOISE_CLIP, NOISE_CLIP)[None]
+    return golden('actors')[tag][[idx]], ref, noise, T
+
+
+def check_noise_case(g, name, fitness, length_t, length_steps, cost_steps, tr, rtol=RTOL):
+    """One episode's outputs against the reference's own Agent.evaluate(is_action_noise, store_transition=True):
+    return <= 1e-5, every cost flag and the critical-buffer routing exact, the stored tuples to f32 (trajectory-level
+    agreement is bounded by the closed loop's amplification of the actor's f32 rounding, as in test_trajectory_*)."""
+    ret = g[name + '_ret']
+    T = int(ret[2])
+    assert int(length_steps) == T and length_t == ret[1]
+    np.testing.assert_allclose(fitness, ret[0], rtol=rtol)
+    np.testing.assert_array_equal(tr[:T, 19].astype(np.int8), g[name + '_cost'])          # SURVEY a7: every info['cost']
+    assert int(cost_steps) == int(g[name + '_ncrit'])
+    np.testing.assert_array_equal(np.nonzero(tr[:T, 19])[0], g[name + '_crit_idx'])
+    # agent.py:93,103: the stored action is the clipped NOISY one (the un-noised actor output is off by up to noise_clip = 0.5)
+    atol = 1e-3 if T > 4000 else 5e-5
+    np.testing.assert_allclose(tr[:T, 7:10], g[name + '_action'], atol=atol)
+    np.testing.assert_allclose(tr[:50, :19], g[name + '_head'], atol=5e-6)
+    np.testing.assert_allclose(tr[T - 50:T, :19], g[name + '_tail'], atol=atol)
+    assert tr[T - 1, 18] == 1.0 and not tr[:T - 1, 18].any()
+
+
+@pytest.mark.parametrize('name,tag,idx,t_max,noisy', NOISE_CASES)
+def test_exploration_noise_and_stored_transitions_vs_reference_python(golden, name, tag, idx, t_max, noisy):
+    from oracle import rollout as R
+    from oracle.smoothness import calc_smoothness
+    w, ref, noise, T = noise_case_inputs(golden, name, tag, idx, t_max, noisy)
+    o = R.rollout(w, NET[tag], [0], ref, t_max=t_max, action_noise=noise, traces=True, transitions=True)
+    g = golden('noise_path')
+    check_noise_case(g, name, o['fitness'][0], o['length_t'][0], o['length_steps'][0], o['cost_steps'][0], o['transitions'][0])
+    np.testing.assert_allclose(calc_smoothness(o['actions'][0][:T]), float(g[name + '_smoothness']), rtol=1e-4)
+    assert int(g[name + '_ret'][3]) == T and int(g[name + '_ret'][4]) == 1      # frames / episodes the reference counted
