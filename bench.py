@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the population-rollout fitness evaluation (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload serl50|serl10|mixed] [--pop MEMBERS_PER_GPU]
+  (N > 1: one rank per GPU over RCCL -- launched by torch.distributed.run, or, when started as a plain
+   `python bench.py --gpus N`, bench.py re-executes itself under torch.distributed.run; fewer than N visible GPUs ->
+   one JSON line {"skipped": ...} and exit code 0)
 
 A "step" is one population evaluation: pop members x num_evals episodes x 8 001 env steps of the
-PH-LAB nominal attitude-tracking task (t_max = 80 s), SERL50 actor shape (7-32-32-32-32-3, tanh),
-weights and reference tables already resident in HBM.  Weak scaling: every GPU evaluates its own
-block of `pop` members (shipped SERL50 actors, tiled with seeded noise beyond the first 50) and the
-per-member result rows are all-gathered.  Prints ONE JSON line on rank 0.
+PH-LAB attitude-tracking task (t_max = 80 s), weights and reference tables already resident in HBM.
+Weak scaling: every GPU evaluates its own block of `pop` members (shipped actors, tiled with seeded noise
+beyond the shipped ones) and the per-member result rows are all-gathered (RCCL).  Prints ONE JSON line on rank 0.
+
+Workloads (BASELINE.json configs): serl50 = config 3 (the metric's configuration, default: pop=50, actor 7-32x4-3;
+--pop 64 is one GPU's share of config 4, pop=512 over 8), serl10 = config 2 (pop=10, actor 7-72x4-3), mixed = one
+GPU's share of config 5 (fault mode per episode = e mod 6 over be/jr/sa/se/ice/cg; default --pop 256).
 """
-import argparse, json, os, sys, time
+import argparse, json, os, socket, subprocess, sys, time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -20,40 +25,90 @@ B_ALG = 48.0          # algorithmic HBM bytes per env-step: ref[k] 3 f64 read + 
 F_ALG = 24059.0       # f64 arithmetic instructions the reference retires per env-step
 HBM_PEAK = 8.0e12     # B/s, MI355X_MICROARCH.md chip table (6.29e12 measured)
 FP64_PEAK = 78.6e12   # FLOP/s vector f64 (half the 157.3 TF f32 vector rate)
+WORKLOADS = {'serl50': dict(tag='serl50', hidden=32, pop=50), 'serl10': dict(tag='serl10', hidden=72, pop=10),
+             'mixed': dict(tag='serl50', hidden=32, pop=256)}
+MIXED_MODES = ['be', 'jr', 'sa', 'se', 'ice', 'cg']
+REFERENCE = os.environ.get('SERL_REFERENCE', '/root/reference')
 
 
-def make_population(pop, rank, seed=7):
+def make_population(pop, rank, seed=7, tag='serl50'):
+    """Members [rank*pop, (rank+1)*pop) of the benchmark population: the shipped actors, tiled, with seeded N(0, 0.01^2)
+    noise on the 2-D weights of every member beyond the shipped ones.  Deterministic per (rank, pop)."""
     import torch
-    base = np.load(os.path.join(ROOT, 'tests', 'golden', 'actors.npz'))['serl50']   # [50, 3715] shipped actors
-    idx = (np.arange(pop) + rank * pop) % len(base)
-    w = torch.from_numpy(base[idx].copy())
-    if pop > len(base) or rank > 0:
-        from serl_amd import NetSpec
-        spec = NetSpec(7, 3, 32, 3, 'tanh')
-        g = torch.Generator().manual_seed(seed + rank)
-        for off, n in spec.genome_segments():
-            w[:, off:off + n] += 0.01 * torch.randn(pop, n, generator=g)
-        w[:min(pop, len(base)) if rank == 0 else 0] = torch.from_numpy(base[idx[:min(pop, len(base))]]) if rank == 0 else w[:0]
+    from serl_amd import NetSpec
+    base = np.load(os.path.join(ROOT, 'tests', 'golden', 'actors.npz'))[tag]   # [50, 3715] / [10, 16563] shipped actors
+    gid = np.arange(pop) + rank * pop
+    w = torch.from_numpy(base[gid % len(base)].copy())
+    spec = NetSpec(7, 3, WORKLOADS[tag]['hidden'], 3, 'tanh')
+    g = torch.Generator().manual_seed(seed + rank)
+    noise = [0.01 * torch.randn(pop, n, generator=g) for _, n in spec.genome_segments()]
+    fresh = torch.from_numpy(gid >= len(base))
+    for (off, n), z in zip(spec.genome_segments(), noise):
+        w[:, off:off + n] += z * fresh[:, None]
     return w
 
 
-def cpu_baseline(w, ref, num_evals, max_episodes=None):
-    """The CPU port (oracle/rollout_ref.c) on all host cores, same workload (bounded sample)."""
+def cpu_port(w, hidden, ref, moe, faults_of=None, build_of=None):
+    """The C restatement (oracle/rollout_ref.c) on all host cores, the same workload (the whole evaluation once)."""
     from oracle import rollout as R
     cores = os.cpu_count() or 1
-    pop = w.shape[0]
-    E = pop * num_evals
-    moe = np.repeat(np.arange(pop, dtype=np.int32), num_evals)
-    n = E if max_episodes is None else min(E, max_episodes)
-    net = dict(state_dim=7, action_dim=3, hidden=32, num_layers=3, activation='tanh')
+    net = dict(state_dim=7, action_dim=3, hidden=hidden, num_layers=3, activation='tanh')
+    E = len(moe)
     R.rollout(w, net, moe[:cores], ref[:cores], t_max=80.0, threads=cores)       # warm-up (page-in, lib build)
+    fit, ls = np.zeros(E), np.zeros(E, np.int32)
     t0 = time.perf_counter()
-    o = R.rollout(w, net, moe[:n], ref[:n], t_max=80.0, threads=cores)
+    groups = {None: np.arange(E)} if build_of is None else {b: np.nonzero(np.asarray(build_of) == b)[0] for b in dict.fromkeys(build_of)}
+    for b, idx in groups.items():
+        o = R.rollout(w, net, moe[idx], ref[idx], t_max=80.0, threads=cores, **({} if b is None else dict(build=b, faults=[faults_of[e] for e in idx])))
+        fit[idx], ls[idx] = o['fitness'], o['length_steps']
     dt = time.perf_counter() - t0
-    steps = int(o['length_steps'].sum())
+    steps = int(ls.sum())
     return dict(value=steps / dt, unit='env-steps/s', cores=cores, kind='port',
-                sample='%d of %d episodes (8001 steps each) of the same workload, C restatement '
-                       '(oracle/rollout_ref.c) on %d threads, %.1f s wall' % (n, E, cores, dt)), o
+                sample='all %d episodes (8001 steps each) of the same workload, C restatement '
+                       '(oracle/rollout_ref.c) on %d threads, %.1f s wall' % (E, cores, dt)), fit, ls
+
+
+def cpu_baseline(w, hidden, ref, moe, faults_of=None, build_of=None):
+    """the reference's own Python path, one process per host core, where /root/reference exists (build
+    container); the GPU box has no reference tree, so there the C restatement is what can be timed in-run
+    (kind = "port") and the committed build-container measurement of the reference Python travels beside it."""
+    cb, fit, ls = cpu_port(w, hidden, ref, moe, faults_of, build_of)
+    try:
+        committed = json.load(open(os.path.join(ROOT, 'profiles', 'r02_reference_cpu.json')))
+    except Exception:
+        committed = None
+    if os.path.isdir(os.path.join(REFERENCE, 'envs', 'h2000_v90')):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'tools', 'time_reference.py'), '--episodes', '1'],
+                           capture_output=True, text=True, timeout=600)
+        m = json.loads(r.stdout.strip().splitlines()[-1])
+        cb = dict(value=m['env_steps_per_s'], unit='env-steps/s', cores=m['procs'], kind='reference-python',
+                  sample='%d processes x %d full 80 s episodes (after one warm-up each) of the reference\'s unmodified Agent.evaluate, '
+                         '%.1f s wall' % (m['procs'], m['episodes_per_proc'], m['seconds']), port=cb)
+    elif committed is not None:
+        cb['reference_python_build_container'] = {
+            'value': committed['env_steps_per_s'], 'unit': 'env-steps/s', 'cores': committed['procs'],
+            'per_core': committed['env_steps_per_s_per_core'], 'source': 'profiles/r02_reference_cpu.json',
+            'note': 'the reference\'s unmodified Python (Agent.evaluate + CitationEnv + torch Actor + its _citation library), one '
+                    'process per core, timed in the build container (tests/tools/time_reference.py); /root/reference does not '
+                    'exist on the GPU box, so it cannot be re-timed in this run'}
+    return cb, fit, ls
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: become N ranks under torch.distributed.run (RCCL rendezvous on
+    127.0.0.1), or report why not and exit 0."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < a.gpus:
+        print(json.dumps({'skipped': 'needs %d GPUs, %d visible' % (a.gpus, have), 'n_gpus': a.gpus,
+                          'metric': 'env-steps/sec (whole node), pop-rollout eval', 'value': None}))
+        sys.exit(0)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    os.execvpe(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+                                '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:], env)
 
 
 def main():
@@ -61,52 +116,69 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--pop', type=int, default=50, help='members per GPU')
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='serl50')
+    ap.add_argument('--pop', type=int, default=0, help='members per GPU (0 = the workload\'s own)')
     ap.add_argument('--num-evals', type=int, default=3)
     ap.add_argument('--lanes', type=int, default=0, help='episodes per wavefront (0 = auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-partition-check', action='store_true')
     a = ap.parse_args()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(a)
 
     import torch
     import torch.distributed as dist
     import serl_amd
-    from serl_amd import refsignals, metrics, distributed as sd
+    from serl_amd import refsignals, metrics, builds, distributed as sd
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    grouped = 'WORLD_SIZE' in os.environ          # under a launcher, also with one rank: the RCCL path is the one that runs
+    if grouped:
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
 
-    spec = serl_amd.NetSpec(7, 3, 32, 3, 'tanh')
-    pop, ne = a.pop, a.num_evals
+    wl = WORKLOADS[a.workload]
+    spec = serl_amd.NetSpec(7, 3, wl['hidden'], 3, 'tanh')
+    pop, ne = a.pop or wl['pop'], a.num_evals
     E = pop * ne
-    w_host = make_population(pop, rank)
+    w_host = make_population(pop, rank, tag=wl['tag'])
     ref_host = refsignals.synthetic_reference_tables(E, ne, 80, seed=7 + 100000 * rank)
     eng = serl_amd.RolloutEngine(local)
     w = w_host.to(dev)
     ref = torch.from_numpy(ref_host).to(dev)
     moe = np.repeat(np.arange(pop, dtype=np.int32), ne)
     T = ref.shape[1]
+    mixed = a.workload == 'mixed'
+    modes = [MIXED_MODES[e % 6] for e in range(E)] if mixed else None
+
+    def evaluate(wd, refd, moe_, n_members, modes_=None):
+        """one population evaluation on this rank -> (rows f64 [ne, members, ROW] on the device, length_steps, fitness)"""
+        if modes_ is None:
+            out = eng.rollout(wd, spec, moe_, refd, t_max=80.0, traces='actions', lanes_per_wave=a.lanes, sync=False)
+            ls, fit, lt, cs = out['length_steps'], out['fitness'], out['length_t'], out['cost_steps'].double()
+            sm = metrics.calc_smoothness(out['actions'], ls)                          # a11, on device
+            ls_host = None
+        else:      # one launch per dynamics build, side by side on streams of their own (evaluate_pop)
+            r = serl_amd.evaluate_pop(wd, mode=modes_, num_evals=ne, refs=refd, t_max=80, spec=spec, engine=eng)
+            tod = lambda x: torch.as_tensor(np.ascontiguousarray(x.T).reshape(-1), device=dev)
+            fit, sm, lt, cs = tod(r.returns), tod(r.smoothness), tod(r.length_t), tod(r.cost_steps).double()
+            ls = tod(r.length_steps)
+        rows = torch.stack([fit, fit, sm, lt, ls.double(), cs], -1)
+        return rows.view(n_members, ne, sd.ROW).transpose(0, 1).contiguous(), ls, fit
 
     def one_step():
-        """one population evaluation on this rank + the fitness all-gather"""
-        out = eng.rollout(w, spec, moe, ref, t_max=80.0, traces='actions', lanes_per_wave=a.lanes, sync=False)
-        ls = out['length_steps']
-        sm = metrics.calc_smoothness(out['actions'], ls)                          # a11, on device
-        fit = out['fitness']
-        rows = torch.stack([fit, fit, sm, out['length_t'], ls.double(), out['cost_steps'].double()], -1)
-        rows = rows.view(pop, ne, sd.ROW).transpose(0, 1).contiguous()
+        """one population evaluation on this rank + the fitness all-gather + index selection"""
+        rows, ls, fit = evaluate(w, ref, moe, pop, modes)
         g = sd.gather_rows(rows, pop * world, world, rank, device=dev)
         pop_fitness = g[..., 0].mean(0)
         champion = int(torch.argmax(pop_fitness))
-        return out, g, champion
+        return ls, fit, g, champion
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -116,11 +188,11 @@ def main():
     kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out, g, champion = one_step()
-        kernel_ms.append(eng.kernel_ms())      # HIP events around the kernel, on its stream (blocks on the kernel)
+        ls, fit, g, champion = one_step()
+        kernel_ms.append(eng.kernel_ms() if not mixed else eng.last_kernel_ms)   # HIP events around the kernel, on its stream
     barrier()
     dt = time.perf_counter() - t0
-    steps_local = int(out['length_steps'].abs().sum())
+    steps_local = int(ls.abs().sum())
     tt = torch.tensor([dt, float(steps_local)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -129,10 +201,19 @@ def main():
     else:
         steps_total = float(steps_local)
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
     value = steps_total * a.steps / dt
+    res_extra = {}
+    if world > 1 and not a.no_partition_check:
+        # the gathered result of the N-way sharded evaluation must be bit-identical to ONE GPU
+        # evaluating the same pop x world members (rank 0 rebuilds every rank's block: the inputs are deterministic)
+        ws = torch.cat([make_population(pop, r, tag=wl['tag']) for r in range(world)]).to(dev)
+        rs = torch.cat([torch.from_numpy(refsignals.synthetic_reference_tables(E, ne, 80, seed=7 + 100000 * r)) for r in range(world)]).to(dev)
+        rows1, _, _ = evaluate(ws, rs, np.repeat(np.arange(pop * world, dtype=np.int32), ne), pop * world,
+                               None if not mixed else [MIXED_MODES[(e % E) % 6] for e in range(E * world)])
+        res_extra['partition_invariance'] = {'members': pop * world, 'bit_identical_to_one_gpu': bool(torch.equal(rows1, g)),
+                                             'champion': champion}
     # informational (never `value`): the same evaluation when the boundary hands over HOST buffers -- weights and
     # reference tables cross PCIe inside the timed region (pinned memory, one H2D copy each per evaluation)
     w_pin, ref_pin = w_host.pin_memory(), torch.from_numpy(ref_host).pin_memory()
@@ -146,45 +227,53 @@ def main():
     k_ms = float(np.mean(kernel_ms))
     ach_hbm = steps_local * B_ALG / (k_ms * 1e-3)
     ach_f64 = steps_local * F_ALG / (k_ms * 1e-3)
-    # HBM traffic of one launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-    # collected and corrected as MI355X_MICROARCH.md prescribes); only quoted for the configuration it was measured on
-    traffic = None
+    # HBM traffic of one launch and the issue-slot occupancy from the PMC passes committed under profiles/ (rocprofv3 --pmc,
+    # collected and corrected as MI355X_MICROARCH.md prescribes); only quoted for the configuration they were measured on
+    traffic, issue = None, None
     try:
-        pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01_k_pmc_traffic.json')))
-        if pop == 50 and ne == 3 and a.lanes == 0:
-            traffic = pm['traffic_bytes_per_launch']
+        pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_current.json')))
+        if pm.get('workload') == a.workload and pm.get('pop') == pop and ne == 3 and a.lanes == 0:
+            traffic, issue = pm.get('traffic_bytes_per_launch'), pm.get('issue')
     except Exception:
         pass
+    name = {'serl50': 'PH-LAB nominal h2000_v90, pop=%d (SERL50 actor 7-32x4-3 tanh)',
+            'serl10': 'PH-LAB nominal h2000_v90, pop=%d (SERL10 actor 7-72x4-3 tanh)',
+            'mixed': 'PH-LAB mixed-fault sweep (be/jr/sa/se/ice/cg by episode), pop=%d (SERL50 actor shape)'}[a.workload] % pop
     res = {
-        'metric': 'env-steps/sec (whole node), pop-rollout eval, pop=%d nominal per GPU' % pop,
+        'metric': 'env-steps/sec (whole node), pop-rollout eval, pop=%d %s per GPU' % (pop, 'mixed-fault' if mixed else 'nominal'),
         'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
         'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': 'PH-LAB nominal h2000_v90, pop=%d (SERL50 actor 7-32x4-3 tanh) x num_evals=%d x 8001 steps '
-                               '(t_max=80 s) per GPU; shipped SERL50 weights (tiled+noise beyond 50), seeded '
-                               'smoothed-step references' % (pop, ne),
+        'config': {'workload': '%s x num_evals=%d x 8001 steps (t_max=80 s) per GPU; shipped weights (tiled+noise beyond the '
+                               'shipped ones), seeded smoothed-step references' % (name, ne),
                    'pop_per_gpu': pop, 'num_evals': ne, 'episodes_per_gpu': E, 'steps_per_episode': T,
                    'lanes_per_wave': a.lanes, 'parallelism': 'member-sharded dp%d' % world},
         'kernel_ms': k_ms,
         'roofline': {'bound': 'hbm', 'achieved': ach_hbm / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                      'frac': ach_hbm / HBM_PEAK, 'traffic': traffic,
-                     'note': 'path is instruction-issue / dependent-latency bound on four wavefronts per episode, not HBM-bound (DESIGN.md): '
-                             'algorithmic traffic is 48 B per env-step; achieved = steps x 48 B / kernel time; traffic = bytes '
-                             'per launch from profiles/r01_k_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE)'},
+                     'note': 'path is instruction-issue / dependent-latency bound (DESIGN.md), not HBM-bound: algorithmic traffic is '
+                             '48 B per env-step; achieved = steps x 48 B / kernel time; traffic = bytes per launch from '
+                             'profiles/pmc_current.json (2 x FETCH_SIZE + WRITE_SIZE)'},
         'roofline_fp64': {'bound': 'valu-f64', 'achieved': ach_f64 / 1e12, 'peak': FP64_PEAK / 1e12, 'unit': 'TFLOP/s',
                           'frac': ach_f64 / FP64_PEAK},
+        'roofline_issue': issue,
         't_step_us': k_ms * 1e3 / T,
         'value_host_buffers': value_host,      # this rank, inputs crossing PCIe per evaluation (informational)
     }
+    res.update(res_extra)
     if not a.no_cpu_baseline:
-        cb, o = cpu_baseline(w_host.numpy(), ref_host, ne)
+        build_of = faults_of = None
+        if mixed:
+            rs_ = [builds.resolve_mode(m) for m in modes]
+            build_of, faults_of = [r[0] for r in rs_], [list(r[1]) for r in rs_]
+        cb, fit_cpu, ls_cpu = cpu_baseline(w_host.numpy(), wl['hidden'], ref_host, moe, faults_of, build_of)
         res['cpu_baseline'] = cb
-        fit_gpu = out['fitness'].cpu().numpy()
-        rel = np.abs(fit_gpu - o['fitness']) / np.abs(o['fitness'])
+        fit_gpu = fit.cpu().numpy()
+        rel = np.abs(fit_gpu - fit_cpu) / np.abs(fit_cpu)
         res['parity_vs_cpu_port'] = {'max_rel_fitness': float(rel.max()),
-                                     'lengths_equal': bool((out['length_steps'].cpu().numpy() == o['length_steps']).all())}
+                                     'lengths_equal': bool((ls.cpu().numpy() == ls_cpu).all())}
     print(json.dumps(res))
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

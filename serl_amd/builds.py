@@ -30,6 +30,7 @@ MODES = {
     'cg-shift': ('cg_timed', NOMINAL_ROW), 'cg-timed': ('cg_timed', NOMINAL_ROW),
     'gust': ('gust', NOMINAL_ROW),
     'noise': ('h2000_v90', NOMINAL_ROW),                # the nominal binary behind the sensor model of envs/noise/citation.py
+    'test': ('test', NOMINAL_ROW),
 }
 # modes whose SWIG wrapper adds the sensor model to what step() returns (envs/noise/citation.py:71-82,
 # envs/gust/citation.py:72-86); the evaluator feeds the kernel a pre-drawn table (sensor_noise_table)
@@ -37,10 +38,24 @@ SENSOR_NOISE_MODES = ('noise', 'gust')
 
 
 def mode_key(mode):
+    """Key of MODES for a mode / env name, following the if-chain of envs/phlabenv.py:99-172 in its order: the first
+    branch matches 'nominal' exactly or any name CONTAINING 'h2000-v90'; the last one any name containing 'test';
+    every other branch compares the lower-cased name for equality.  Env names split like envs/config.py:16-25
+    ('PHlab_attitude_<mode>'; two tokens = empty mode, which the reference rejects)."""
     m = mode
     if m.lower().startswith('phlab_'):
-        m = m.split('_', 2)[2]
-    return m.lower()
+        toks = m.lower().split('_')
+        m = toks[2] if len(toks) == 3 else ''
+    if 'incremental' in m.lower():
+        # envs/phlabenv.py:174-176,377-380: incremental control integrates the action (last_u + a*dt) and widens the
+        # observation; the kernel implements the attitude configuration with direct deflection commands only
+        raise NotImplementedError('PH-LAB incremental-control modes (%r) are not supported by the GPU evaluator' % mode)
+    if m == 'nominal' or 'h2000-v90' in m.lower():
+        return 'nominal'
+    m = m.lower()
+    if m not in MODES and 'test' in m:
+        return 'test'
+    return m
 
 
 def has_sensor_noise(mode):
@@ -83,10 +98,7 @@ def load(build):
 
 def resolve_mode(mode):
     """'nominal' | 'be' | 'PHlab_attitude_ice' ... -> (build, fault_row)"""
-    m = mode
-    if m.lower().startswith('phlab_'):
-        m = m.split('_', 2)[2]
-    m = m.lower()
+    m = mode_key(mode)
     if m not in MODES:
         raise ValueError('unknown PH-LAB mode %r (known: %s)' % (mode, ', '.join(sorted(MODES))))
     return MODES[m]

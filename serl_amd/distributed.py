@@ -27,7 +27,7 @@ def gather_rows(local_rows, pop, world_size, rank, device=None):
     num_evals = local_rows.shape[0]
     buf = torch.zeros(num_evals, per, ROW, dtype=torch.float64, device=device or local_rows.device)
     buf[:, :local_rows.shape[1]] = local_rows
-    if world_size == 1 or not dist.is_initialized():
+    if not dist.is_initialized():        # (a one-rank group still goes through the collective: the same code path as N ranks)
         return buf[:, :pop].clone()
     out = [torch.empty_like(buf) for _ in range(world_size)]
     dist.all_gather(out, buf)

@@ -67,3 +67,63 @@ def test_member_blocks_cover_population():
             blocks = [sd.member_block(pop, ws, r) for r in range(ws)]
             assert blocks[0][0] == 0 and blocks[-1][1] == pop
             assert all(blocks[i][1] == blocks[i + 1][0] for i in range(ws - 1))
+
+
+_NCCL_ONE_RANK = r'''
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import serl_amd
+from serl_amd import refsignals, distributed as sd
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=%(port)r, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+torch.cuda.set_device(0)
+dev = torch.device('cuda', 0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)      # nccl == RCCL on ROCm
+w = torch.from_numpy(np.load(os.path.join(%(root)r, 'tests', 'golden', 'actors.npz'))['serl50'][:5])
+spec = serl_amd.NetSpec(7, 3, 32, 3, 'tanh')
+refs = refsignals.synthetic_reference_tables(10, 2, 20, seed=7)
+eng = serl_amd.RolloutEngine(0)
+def local(lo, hi):
+    r = serl_amd.evaluate_pop(w[lo:hi], spec=spec, num_evals=2, refs=refs[lo * 2:hi * 2], t_max=20, engine=eng)
+    return dict(fitness=r.fitness, returns=r.returns, smoothness=r.smoothness, length_t=r.length_t,
+                length_steps=r.length_steps, cost_steps=r.cost_steps)
+g = sd.evaluate_pop_sharded(local, 5, 2, device=dev)          # all_gather over the RCCL communicator
+one = serl_amd.evaluate_pop(w, spec=spec, num_evals=2, refs=refs, t_max=20, engine=eng)
+t = torch.ones(4, device=dev, dtype=torch.float64); dist.all_reduce(t); dist.barrier()
+print(json.dumps(dict(same=bool(np.array_equal(g['fitness'], one.fitness) and np.array_equal(g['length_steps'], one.length_steps)),
+                      champion=[g['champion'], one.champion], backend=dist.get_backend(), allreduce=float(t.sum()))))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_sharded_evaluation_over_a_one_rank_rccl_group():
+    """The RCCL code path (init with device_id, all_gather of the result rows on the device, all_reduce, barrier) on the
+    one GPU a test box has: world size 1, backend nccl, in a process of its own."""
+    import subprocess, json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    r = subprocess.run([sys.executable, '-c', _NCCL_ONE_RANK % dict(root=ROOT, port=str(29600 + os.getpid() % 2000))],
+                       capture_output=True, text=True, timeout=500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res['same'] and res['champion'][0] == res['champion'][1] and res['backend'] == 'nccl' and res['allreduce'] == 4.0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_bench_starts_itself_for_n_gpus_or_says_why_not():
+    """`python bench.py --gpus N` without a launcher: with fewer than N GPUs one JSON line {"skipped": ...}, exit code 0;
+    under torch.distributed.run with one rank the RCCL bench path runs end to end."""
+    import subprocess, json
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n + 1)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert 'skipped' in json.loads(r.stdout.strip().splitlines()[-1])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                        '--master-port', str(29700 + os.getpid() % 2000), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '1',
+                        '--warmup', '0', '--pop', '4', '--no-cpu-baseline'], capture_output=True, text=True, timeout=500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and line['value'] > 0
