@@ -106,7 +106,7 @@ def test_sharded_evaluation_over_a_one_rank_rccl_group():
     r = subprocess.run([sys.executable, '-c', _NCCL_ONE_RANK % dict(root=ROOT, port=str(29600 + os.getpid() % 2000))],
                        capture_output=True, text=True, timeout=500, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    res = json.loads(r.stdout.strip().splitlines()[-1])
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])      # (RCCL prints its library path on stdout)
     assert res['same'] and res['champion'][0] == res['champion'][1] and res['backend'] == 'nccl' and res['allreduce'] == 4.0
 
 
@@ -119,7 +119,7 @@ def test_bench_starts_itself_for_n_gpus_or_says_why_not():
     n = torch.cuda.device_count()
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n + 1)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert 'skipped' in json.loads(r.stdout.strip().splitlines()[-1])
+    assert 'skipped' in json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
                         '--master-port', str(29700 + os.getpid() % 2000), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '1',
