@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SERL_ABI_VERSION 3
+#define SERL_ABI_VERSION 4
 
 enum serl_error {
   SERL_OK = 0,
@@ -139,6 +139,9 @@ const char *serl_last_error(void);
 int serl_ctx_create(int device, serl_ctx **out);
 int serl_ctx_destroy(serl_ctx *ctx);
 int serl_ctx_load_build(serl_ctx *ctx, int slot, const serl_build_desc *build);
+/* The development switches (SERL_TEAM, SERL_WAVES_PER_BLOCK, SERL_HALF, SERL_PROFILE) are read from the environment once,
+ * by serl_ctx_create; this re-reads them (A/B tests flip them between calls). */
+int serl_ctx_refresh_env(serl_ctx *ctx);
 
 /* One population evaluation: all episodes of the descriptor, one fused kernel launch per call. */
 int serl_rollout(serl_ctx *ctx, const serl_rollout_desc *desc, void *stream);
@@ -181,6 +184,35 @@ int serl_ga_mutate(serl_ctx *ctx, float *weights, int64_t stride, int32_t member
 int serl_ga_scaled_perturb(serl_ctx *ctx, float *weights, int64_t stride, int32_t member,
                            const int32_t *seg_offset, const int32_t *seg_length, int32_t n_seg,
                            const float *delta, const float *scaling, void *stream);
+
+/* Output sensitivity of proximal_mutate / safe_mutate (mod_neuro_evo.py:183-223, 254-298): for every listed member,
+ *   jacobian_i = d( sum_b actor(states[m][b])[i] ) / d genome,  i < action_dim   (the reference: one backward pass per output)
+ *   scaling    = sqrt(sum_i jacobian_i^2);  scaling[scaling == 0] = 1;  scaling[scaling < 0.01] = 0.01
+ * genome = the 2-D weights in named_parameters order (extract_parameters, genetic_agent.py:131-141), G = H*S + L*H*H + A*H.
+ * states: f32 [n_members][batch][state_dim], scaling: f32 [n_members][G] (device).  The update itself is
+ * serl_ga_scaled_perturb with delta drawn by the host (torch.distributions.Normal, the reference's generator). */
+int serl_ga_sensitivity(serl_ctx *ctx, const float *weights, int64_t stride, int32_t state_dim, int32_t hidden,
+                        int32_t num_layers, int32_t action_dim, int32_t activation, const int32_t *members,
+                        int32_t n_members, const float *states, int32_t batch, float *scaling, void *stream);
+/* Actor.get_novelty (genetic_agent.py:111-115) for n_pairs (actor, batch) pairs in one launch:
+ *   novelty[p] = mean_b sum_a (actions[p][b][a] - actor_{members[p]}(states[p][b])[a])^2
+ * -- the two halves of SSNE.get_distance (mod_neuro_evo.py:411-417), i.e. the keys of sort_groups_by_distance (:426-445). */
+int serl_ga_novelty(serl_ctx *ctx, const float *weights, int64_t stride, int32_t state_dim, int32_t hidden,
+                    int32_t num_layers, int32_t action_dim, int32_t activation, const int32_t *members, int32_t n_pairs,
+                    const float *states, const float *actions, int32_t batch, float *novelty, void *stream);
+
+/* ---- device replay rings (base/core/replay_memory.py:21-31 `add`, base/core/agent.py:101-112) ---------------------------
+ * A ring is f32 [capacity][20] rows (obs7, a3, next_obs7, r, done, cost) in HBM.  One job appends the rows of one stored
+ * episode -- staged[episode][0 .. length), what serl_rollout wrote to `transitions` -- to ring slots
+ * (position + k) % capacity in step order, k = rank of the row among the rows taken: all of them, or (cost_only) the
+ * cost-flagged ones, compacted (agent.critical_buffer).  The first `skip` ranks are not written (an episode longer than
+ * the ring leaves only its tail, as sequential add() calls would).  The host keeps position / fill of every ring. */
+typedef struct serl_replay_job {
+  float *ring;
+  int32_t capacity, position, episode, length, cost_only, skip;
+} serl_replay_job;
+int serl_replay_scatter(serl_ctx *ctx, const float *staged, int64_t rows_per_episode, const serl_replay_job *jobs /* device */,
+                        int32_t n_jobs, void *stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,8 @@ LIB_PATH = os.environ.get('SERL_LIB') or os.path.join(os.path.dirname(os.path.ab
 
 EXPORTS = ['serl_abi_version', 'serl_last_error', 'serl_param_count', 'serl_ctx_create', 'serl_ctx_destroy',
            'serl_ctx_load_build', 'serl_rollout', 'serl_dyn_open_loop', 'serl_debug_profile', 'serl_last_rollout_ms', 'serl_ga_clone', 'serl_ga_crossover',
-           'serl_ga_mutate', 'serl_ga_scaled_perturb']
+           'serl_ga_mutate', 'serl_ga_scaled_perturb', 'serl_ctx_refresh_env', 'serl_ga_sensitivity', 'serl_ga_novelty',
+           'serl_replay_scatter']
 
 
 class BuildDesc(ctypes.Structure):
@@ -61,10 +62,15 @@ def lib():
     L.serl_ga_crossover.argtypes = [VP, VP, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, VP, ctypes.c_int32, VP]
     L.serl_ga_mutate.argtypes = [VP, VP, ctypes.c_int64, ctypes.c_int32, VP, VP, VP, VP, ctypes.c_int32, VP]
     L.serl_ga_scaled_perturb.argtypes = [VP, VP, ctypes.c_int64, ctypes.c_int32, VP, VP, ctypes.c_int32, VP, VP, VP]
+    L.serl_ctx_refresh_env.argtypes = [VP]
+    i32 = ctypes.c_int32
+    L.serl_ga_sensitivity.argtypes = [VP, VP, ctypes.c_int64, i32, i32, i32, i32, i32, VP, i32, VP, i32, VP, VP]
+    L.serl_ga_novelty.argtypes = [VP, VP, ctypes.c_int64, i32, i32, i32, i32, i32, VP, i32, VP, VP, i32, VP, VP]
+    L.serl_replay_scatter.argtypes = [VP, VP, ctypes.c_int64, VP, i32, VP]
     for f in EXPORTS:
         if f not in ('serl_last_error',):
             getattr(L, f).restype = ctypes.c_int
-    if L.serl_abi_version() != 3:
+    if L.serl_abi_version() != 4:
         raise RuntimeError('serl_amd: ABI version mismatch')
     _lib = L
     return L

@@ -8,34 +8,11 @@
 #include <string>
 #include <vector>
 #include "rollout_device.h"
-
-#define SERL_MAX_SLOTS 16
+#include "serl_ctx.h"
 
 static thread_local std::string g_err;
-static int fail(int code, const std::string &msg) { g_err = msg; return code; }
-#define HIP_TRY(expr)                                                                           \
-  do {                                                                                          \
-    hipError_t e_ = (expr);                                                                     \
-    if (e_ != hipSuccess)                                                                       \
-      return fail(SERL_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));               \
-  } while (0)
-
-struct BuildSlot {
-  bool loaded = false;
-  int32_t code = 0;
-  uint64_t ro_base = 0;
-  double dt = 0.01;
-  double *blob = nullptr;   // one device allocation: ro | t3[46] | x0[19] | dw0[31]
-  size_t n_ro = 0;
-};
-
-struct serl_ctx {
-  int device = 0;
-  BuildSlot slots[SERL_MAX_SLOTS];
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool timed = false;
-  unsigned long long *prof = nullptr;   // device [4], allocated when SERL_PROFILE=1
-};
+int serl_fail(int code, const std::string &msg) { g_err = msg; return code; }
+static int fail(int code, const std::string &msg) { return serl_fail(code, msg); }
 
 void serl_launch_rollout_nominal(const RolloutArgs &a, int grid, hipStream_t stream);
 void serl_launch_rollout_ice(const RolloutArgs &a, int grid, hipStream_t stream);
@@ -56,13 +33,11 @@ SERL_DECL_TEAM(nominal) SERL_DECL_TEAM(ice) SERL_DECL_TEAM(cg_timed) SERL_DECL_T
 // ~0.55 of the time a lone wavefront needs (32.7 vs 59 us, four wavefronts), but only one team fits a CU where four lone wavefronts
 // would: teams while every episode gets a CU of its own (measured: 320 episodes as teams 88 us, 400 alone 59 us),
 // lone wavefronts beyond.  SERL_TEAM=0 / 1 overrides.
-static int g_num_cus = 256;       // multiProcessorCount of the context's device (set by serl_ctx_create)
-static bool serl_use_team(int code, int episodes)
+static bool serl_use_team(const serl_ctx *c, int code, int episodes)
 {
   (void)code;
-  const char *env = getenv("SERL_TEAM");
-  if (env) return atoi(env) != 0;
-  return episodes <= g_num_cus;
+  if (c->env_team >= 0) return c->env_team != 0;
+  return episodes <= c->num_cus;
 }
 
 static void serl_launch_rollout_team(int code, const RolloutArgs &a, int grid, hipStream_t stream)
@@ -116,11 +91,10 @@ static void serl_launch_dyn_wave(int code, const RolloutArgs &a, const double *c
 
 // Wavefronts per workgroup of the wave-cooperative kernels: one per CU while there are no more episodes than CUs,
 // then up to four (one per SIMD) sharing the workgroup's LDS copy of the tables.
-static int serl_wave_kernel_waves_per_block(int episodes)
+static int serl_wave_kernel_waves_per_block(const serl_ctx *c, int episodes)
 {
-  const char *env = getenv("SERL_WAVES_PER_BLOCK");     // (8 only with a library built with -DCITW_MAX_WAVES=8)
-  if (env && atoi(env) >= 1 && atoi(env) <= 8) return atoi(env);
-  int w = (episodes + 255) / 256;
+  if (c->env_waves_per_block >= 1 && c->env_waves_per_block <= 8) return c->env_waves_per_block;     // (8 only with a library built with -DCITW_MAX_WAVES=8)
+  int w = (episodes + c->num_cus - 1) / c->num_cus;
   return w < 1 ? 1 : (w > 4 ? 4 : w);
 }
 
@@ -128,14 +102,30 @@ static int serl_wave_kernel_waves_per_block(int episodes)
 // only one workgroup fits a CU: while there are no more wavefronts than CUs each gets a CU of its own (the
 // code streams through the instruction cache and co-resident waves slow each other down); beyond that, waves
 // share a CU four at a time (one per SIMD, each with the full 512-register budget).
-static int serl_waves_per_block(int waves)
+static int serl_waves_per_block(const serl_ctx *c, int waves)
 {
-  const char *env = getenv("SERL_WAVES_PER_BLOCK");
-  if (env && atoi(env) >= 1 && atoi(env) <= 4) return atoi(env);
-  return waves <= 256 ? 1 : 4;
+  if (c->env_waves_per_block >= 1 && c->env_waves_per_block <= 4) return c->env_waves_per_block;
+  return waves <= c->num_cus ? 1 : 4;
+}
+
+// development / A-B switches: read when the context is created and by serl_ctx_refresh_env (tests flip them between calls)
+static void serl_ctx_read_env(serl_ctx *c)
+{
+  const char *e;
+  c->env_team = (e = getenv("SERL_TEAM")) ? atoi(e) : -1;
+  c->env_waves_per_block = (e = getenv("SERL_WAVES_PER_BLOCK")) ? atoi(e) : -1;
+  c->env_half = (e = getenv("SERL_HALF")) ? atoi(e) : -1;
+  c->env_profile = getenv("SERL_PROFILE") != nullptr;
 }
 
 extern "C" {
+
+int serl_ctx_refresh_env(serl_ctx *c)
+{
+  if (!c) return fail(SERL_E_INVALID, "serl_ctx_refresh_env: NULL context");
+  serl_ctx_read_env(c);
+  return SERL_OK;
+}
 
 int serl_abi_version(void) { return SERL_ABI_VERSION; }
 const char *serl_last_error(void) { return g_err.c_str(); }
@@ -152,8 +142,12 @@ int serl_ctx_create(int device, serl_ctx **out)
   c->device = device;
   {
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) g_num_cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+      if (prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
+      if (prop.sharedMemPerBlockOptin > 0) c->lds_per_block = (int)prop.sharedMemPerBlockOptin;
+    }
   }
+  serl_ctx_read_env(c);
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   *out = c;
@@ -167,6 +161,7 @@ int serl_ctx_destroy(serl_ctx *c)
   for (auto &s : c->slots) if (s.blob) (void)hipFree(s.blob);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->prof) (void)hipFree(c->prof);
   delete c;
   return SERL_OK;
 }
@@ -221,7 +216,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   a.ro = s.blob; a.t3 = s.blob + s.n_ro; a.x0 = a.t3 + 46; a.dw0 = a.x0 + 19;
   a.dyn_dt = s.dt;
   a.prof = nullptr;
-  if (getenv("SERL_PROFILE")) {
+  if (c->env_profile) {
     if (!c->prof) HIP_TRY(hipMalloc((void **)&c->prof, 32 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(c->prof, 0, 32 * sizeof(unsigned long long), stream));
     a.prof = c->prof;
@@ -231,7 +226,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   // not recorded for them (an event in flight on one stream must not be re-recorded on another)
   const bool timed = d->concurrent_episodes <= 0;
   const int together = d->n_episodes + (d->concurrent_episodes > 0 ? d->concurrent_episodes : 0);   // episodes sharing the GPU
-  if (lanes <= 0 && serl_use_team(s.code, together)) {
+  if (lanes <= 0 && serl_use_team(c, s.code, together)) {
     a.lanes = 1;
     a.block = 128;
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
@@ -244,7 +239,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   if (lanes <= 0 && serl_has_wave_kernel(s.code)) {
     // default: one wavefront per episode (model glue wave-uniform, look-ups / actor rows / ODE5 states per lane)
     // side-by-side launches round their workgroup counts up separately: leave room for a few partial workgroups
-    const int wpb = serl_wave_kernel_waves_per_block(together + (timed ? 0 : 16));
+    const int wpb = serl_wave_kernel_waves_per_block(c, together + (timed ? 0 : 16));
     a.lanes = 1;
     a.block = 64 * wpb;
     const int grid = (d->n_episodes + wpb - 1) / wpb;
@@ -267,7 +262,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   if (lanes > 64) lanes = 64;
   a.lanes = lanes;
   const int waves = (d->n_episodes + lanes - 1) / lanes;
-  const int wpb = serl_waves_per_block(waves);
+  const int wpb = serl_waves_per_block(c, waves);
   a.block = 64 * wpb;
   const int grid = (waves + wpb - 1) / wpb;
   if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
@@ -292,7 +287,7 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
   a.ro = s.blob; a.t3 = s.blob + s.n_ro; a.x0 = a.t3 + 46; a.dw0 = a.x0 + 19;
   a.dyn_dt = s.dt;
   hipStream_t stream = (hipStream_t)stream_;
-  if (lanes_per_wave <= 0 && serl_use_team(s.code, n_episodes)) {
+  if (lanes_per_wave <= 0 && serl_use_team(c, s.code, n_episodes)) {
     a.lanes = 1;
     a.block = 128;
     HIP_TRY(hipEventRecord(c->ev0, stream));
@@ -303,7 +298,7 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
     return SERL_OK;
   }
   if (lanes_per_wave <= 0 && serl_has_wave_kernel(s.code)) {
-    const int wpb = serl_wave_kernel_waves_per_block(n_episodes);
+    const int wpb = serl_wave_kernel_waves_per_block(c, n_episodes);
     a.lanes = 1;
     a.block = 64 * wpb;
     HIP_TRY(hipEventRecord(c->ev0, stream));
@@ -319,7 +314,7 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
   if (lanes > 64) lanes = 64;
   a.lanes = lanes;
   const int nwaves = (n_episodes + lanes - 1) / lanes;
-  const int wpb = serl_waves_per_block(nwaves);
+  const int wpb = serl_waves_per_block(c, nwaves);
   a.block = 64 * wpb;
   const int grid = (nwaves + wpb - 1) / wpb;
   HIP_TRY(hipEventRecord(c->ev0, stream));

@@ -1,0 +1,37 @@
+// serl_ctx.h -- internals shared by the translation units behind the C ABI (serl_capi.hip, serl_ga.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/serl_amd.h"
+
+#define SERL_MAX_SLOTS 16
+
+int serl_fail(int code, const std::string &msg);      // records the thread-local message of serl_last_error()
+#define HIP_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return serl_fail(SERL_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+
+struct BuildSlot {
+  bool loaded = false;
+  int32_t code = 0;
+  uint64_t ro_base = 0;
+  double dt = 0.01;
+  double *blob = nullptr;   // one device allocation: ro | t3[46] | x0[19] | dw0[31]
+  size_t n_ro = 0;
+};
+
+struct serl_ctx {
+  int device = 0;
+  int num_cus = 256;                    // multiProcessorCount of this context's device
+  int lds_per_block = 65536;            // sharedMemPerBlockOptin
+  // environment overrides, read once when the context is made (-1 = not set)
+  int env_team = -1, env_waves_per_block = -1, env_profile = 0, env_half = -1;
+  BuildSlot slots[SERL_MAX_SLOTS];
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  unsigned long long *prof = nullptr;   // device [32], allocated when SERL_PROFILE=1
+};

@@ -121,3 +121,100 @@ def scaled_perturb(engine, weights, member, spec: NetSpec, delta, scaling):
     _capi.check(engine.lib.serl_ga_scaled_perturb(engine.ctx, weights.data_ptr(), weights.stride(0), int(member),
                                                   so.data_ptr(), sl.data_ptr(), len(segs), dl.data_ptr(), sc.data_ptr(),
                                                   _stream(dev)), 'serl_ga_scaled_perturb')
+
+
+# ---- operators that need the actor itself (kernels in csrc/serl_ga.hip) ----------------------------------------------------
+def _net_args(spec: NetSpec):
+    return (spec.state_dim, spec.hidden, spec.num_layers, spec.action_dim, spec.activation_id)
+
+
+def genome_size(spec: NetSpec):
+    return sum(n for _, n in spec.genome_segments())
+
+
+def sensitivity(engine, weights, members, spec: NetSpec, states):
+    """The clamped output sensitivity of proximal_mutate / safe_mutate (mod_neuro_evo.py:188-217) for several members at
+    once: states f32 [n, B, state_dim] (device) -> scaling f32 [n, G] (device)."""
+    dev = weights.device
+    members = np.atleast_1d(np.asarray(members, dtype=np.int32))
+    states = torch.as_tensor(states, dtype=torch.float32).to(dev).contiguous()
+    n, B = states.shape[0], states.shape[1]
+    assert n == len(members) and states.shape[2] == spec.state_dim
+    G = genome_size(spec)
+    if B == 0:            # empty buffer: every gradient is zero -> scaling[scaling == 0] = 1
+        return torch.ones(n, G, dtype=torch.float32, device=dev)
+    out = torch.empty(n, G, dtype=torch.float32, device=dev)
+    m = _i32(dev, members)
+    _capi.check(engine.lib.serl_ga_sensitivity(engine.ctx, weights.data_ptr(), weights.stride(0), *_net_args(spec), m.data_ptr(), n,
+                                               states.data_ptr(), B, out.data_ptr(), _stream(dev)), 'serl_ga_sensitivity')
+    return out
+
+
+def draw_delta(spec: NetSpec, mag):
+    """the initial perturbation of mod_neuro_evo.py:195-197, drawn from torch's global CPU generator like the reference
+    (whose `params` live on the CPU): Normal(zeros(G), ones(G) * mag).sample()"""
+    import torch.distributions as dist
+    G = genome_size(spec)
+    return dist.Normal(torch.zeros(G), torch.ones(G) * mag).sample()
+
+
+def proximal_mutate(engine, weights, member, spec: NetSpec, mag, buffer, batch_size, rng=random, delta=None):
+    """SSNE.proximal_mutate (mod_neuro_evo.py:183-223) on the device-resident population: the batch is what the
+    reference's `gene.buffer.sample(min(mutation_batch_size, len(buffer)))` picks (same python `random` draws), the
+    sensitivity comes from serl_ga_sensitivity, delta from torch's generator, the update is serl_ga_scaled_perturb.
+    `buffer` is a replay.DeviceReplay.  safe_mutate (:254-298) is the same operator fed from the critical buffer."""
+    states = buffer.sample(min(int(batch_size), len(buffer)), rng)[0]
+    scaling = sensitivity(engine, weights, [int(member)], spec, states[None])[0]
+    delta = draw_delta(spec, mag) if delta is None else delta
+    scaled_perturb(engine, weights, int(member), spec, delta, scaling)
+    return scaling
+
+
+def safe_mutate(engine, weights, member, spec: NetSpec, mag, buffer, critical_buffer, batch_size, rng=random, delta=None):
+    src = critical_buffer if len(critical_buffer) > 1 else buffer          # mod_neuro_evo.py:258-261
+    return proximal_mutate(engine, weights, member, spec, mag, src, batch_size, rng, delta)
+
+
+def novelty(engine, weights, members, spec: NetSpec, states, actions):
+    """Actor.get_novelty (genetic_agent.py:111-115) for n (actor, batch) pairs: states [n, B, S], actions [n, B, A]
+    -> f32 [n] (device)"""
+    dev = weights.device
+    members = np.atleast_1d(np.asarray(members, dtype=np.int32))
+    states = torch.as_tensor(states, dtype=torch.float32).to(dev).contiguous()
+    actions = torch.as_tensor(actions, dtype=torch.float32).to(dev).contiguous()
+    n, B = states.shape[0], states.shape[1]
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    m = _i32(dev, members)
+    _capi.check(engine.lib.serl_ga_novelty(engine.ctx, weights.data_ptr(), weights.stride(0), *_net_args(spec), m.data_ptr(), n,
+                                           states.data_ptr(), actions.data_ptr(), B, out.data_ptr(), _stream(dev)), 'serl_ga_novelty')
+    return out
+
+
+def sort_groups_by_distance(engine, weights, genomes, buffers, spec: NetSpec, rng=random):
+    """SSNE.sort_groups_by_distance (mod_neuro_evo.py:426-445): every pair (i < j in list order) of `genomes` keyed by
+    get_distance = gene1.get_novelty(batch of gene2) + gene2.get_novelty(batch of gene1), batches of
+    min(256, len(buffer1), len(buffer2)) from the latest 1000 tuples of each buffer (same python `random` draws, in the
+    reference's order); all 2 * pairs forward batches in ONE launch.  -> [(second, first, distance)] sorted descending."""
+    pairs, members, st, ac = [], [], [], []
+    for i, first in enumerate(genomes):
+        for second in genomes[i + 1:]:
+            b1, b2 = buffers[first], buffers[second]
+            bs = min(256, min(len(b1), len(b2)))
+            s1, a1, _, _, _ = b1.sample_from_latest(bs, 1000, rng)
+            s2, a2, _, _, _ = b2.sample_from_latest(bs, 1000, rng)
+            pairs.append((second, first, bs))
+            members += [first, second]                     # gene1 judged on gene2's batch, gene2 on gene1's
+            st += [s2, s1]; ac += [a2, a1]
+    if not pairs:
+        return []
+    sizes = {p[2] for p in pairs}
+    if len(sizes) == 1:
+        nov = novelty(engine, weights, members, spec, torch.stack(st), torch.stack(ac)).cpu().numpy().astype(np.float64)
+    else:               # buffers of different fill: one launch per batch size
+        nov = np.zeros(len(members), dtype=np.float64)
+        for bs in sizes:
+            idx = [k for k in range(len(members)) if pairs[k // 2][2] == bs]
+            nov[idx] = novelty(engine, weights, [members[k] for k in idx], spec, torch.stack([st[k] for k in idx]),
+                               torch.stack([ac[k] for k in idx])).cpu().numpy()
+    groups = [(p[0], p[1], float(nov[2 * k]) + float(nov[2 * k + 1])) for k, p in enumerate(pairs)]   # two .item() floats added in f64
+    return sorted(groups, key=lambda g: g[2], reverse=True)

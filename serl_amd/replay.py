@@ -1,0 +1,138 @@
+"""Device-resident replay rings behind the reference's `ReplayMemory` call shapes (base/core/replay_memory.py:12-103).
+
+The reference keeps a Python list of `Transition` tuples per buffer (shared buffer of the RL learner, `buffer` and
+`critical_buffer` of every GeneticAgent) and appends to it one tuple per env step (base/core/agent.py:101-112).  Here a
+buffer is one f32 tensor `rows[capacity, 20]` in HBM -- the row layout the rollout kernel writes,
+(obs[7], action[3], next_obs[7], reward, done, cost) -- and whole episodes are appended by ONE scatter kernel
+(`serl_replay_scatter`, include/serl_amd.h): every stored episode of a generation to the shared ring, to its agent's
+ring, and its cost-flagged rows compacted into the agent's critical ring.  Nothing crosses to the host per step.
+
+Index semantics are the reference's, slot for slot, and every random draw is made on the host from the same python
+`random` stream (`random.sample` / `random.shuffle` consume the generator as a function of the list LENGTH only, so
+drawing over `range(len)` reproduces the reference's choices): `sample`, `sample_from_latest`, `get_latest`,
+`add_content_of`, `add_latest_from`, `shuffle`, `reset` select the same transitions as the list-backed class.
+"""
+import ctypes, random
+import numpy as np
+import torch
+
+ROW = 20          # obs7 | action3 | next_obs7 | reward | done | cost
+
+
+class DeviceReplay:
+    """Uniform replay ring on the GPU with the interface of replay_memory.ReplayMemory."""
+
+    def __init__(self, capacity, device, engine=None):
+        self.capacity = int(capacity)
+        self.device = torch.device(device)
+        self.engine = engine
+        self.rows = torch.zeros(self.capacity, ROW, dtype=torch.float32, device=self.device)
+        self.position = 0
+        self.size = 0
+
+    def __len__(self):
+        return self.size
+
+    def reset(self):
+        self.position, self.size = 0, 0
+
+    # ---- appends ----------------------------------------------------------------------------------------------
+    def _advance(self, n):
+        """book-keeping of n sequential add() calls (replay_memory.py:21-31); -> (first slot, rows to skip)"""
+        first = self.position
+        self.size = min(self.capacity, self.size + n)
+        self.position = (self.position + n) % self.capacity
+        return first, max(0, n - self.capacity)
+
+    def add(self, obs, action, next_obs, reward, done, cost=0.0):
+        """one tuple from the host (the reference's call shape; the batched path is `append_rows` / `scatter_episodes`)"""
+        r = np.concatenate([np.asarray(obs, np.float32).reshape(-1), np.asarray(action, np.float32).reshape(-1),
+                            np.asarray(next_obs, np.float32).reshape(-1), [np.float32(reward)], [np.float32(done)], [np.float32(cost)]])
+        self.append_rows(torch.from_numpy(r.astype(np.float32))[None])
+
+    def append_rows(self, rows):
+        """rows f32 [n, 20] (device or host), appended in order like n calls of add()"""
+        rows = torch.as_tensor(rows, dtype=torch.float32).to(self.device)
+        n = rows.shape[0]
+        if n == 0:
+            return
+        first, skip = self._advance(n)
+        slots = (first + torch.arange(skip, n, device=self.device)) % self.capacity
+        self.rows.index_copy_(0, slots, rows[skip:])
+
+    # ---- views in the reference's order ------------------------------------------------------------------------
+    def latest_slots(self, latest):
+        """physical slots of ReplayMemory.get_latest(latest) (replay_memory.py:42-56), most recent last"""
+        n, p, cap = self.size, self.position, self.capacity
+        mem = list(range(n))
+        if cap < latest:
+            out = mem[p:] + mem[:p]
+        elif n < cap:
+            out = mem[-latest:]
+        elif p >= latest:
+            out = mem[:p][-latest:]
+        else:
+            out = mem[-latest + p:] + mem[:p]
+        return out
+
+    def get_latest(self, latest):
+        return self.rows[torch.as_tensor(self.latest_slots(latest), dtype=torch.int64, device=self.device)]
+
+    def add_content_of(self, other):
+        self.append_rows(other.get_latest(self.capacity))
+
+    def add_latest_from(self, other, latest):
+        self.append_rows(other.get_latest(latest))
+
+    def shuffle(self, rng=random):
+        """random.shuffle(self.memory): the same permutation, applied to the rows"""
+        perm = list(range(self.size))
+        rng.shuffle(perm)
+        if self.size:
+            self.rows[:self.size] = self.rows[torch.as_tensor(perm, dtype=torch.int64, device=self.device)]
+
+    # ---- sampling ----------------------------------------------------------------------------------------------
+    @staticmethod
+    def split(rows):
+        """rows [B, 20] -> (state [B,7], action [B,3], next_state [B,7], reward [B,1], done [B,1]) like ReplayMemory.sample"""
+        return rows[:, 0:7], rows[:, 7:10], rows[:, 10:17], rows[:, 17:18], rows[:, 18:19]
+
+    def sample_slots(self, batch_size, rng=random):
+        return rng.sample(range(self.size), batch_size)
+
+    def sample(self, batch_size, rng=random):
+        idx = self.sample_slots(batch_size, rng)
+        return self.split(self.rows[torch.as_tensor(idx, dtype=torch.int64, device=self.device)])
+
+    def sample_from_latest(self, batch_size, latest, rng=random):
+        slots = self.latest_slots(latest)
+        pick = rng.sample(range(len(slots)), batch_size)
+        return self.split(self.rows[torch.as_tensor([slots[i] for i in pick], dtype=torch.int64, device=self.device)])
+
+
+class _Job(ctypes.Structure):
+    _fields_ = [('ring', ctypes.c_void_p), ('capacity', ctypes.c_int32), ('position', ctypes.c_int32),
+                ('episode', ctypes.c_int32), ('length', ctypes.c_int32), ('cost_only', ctypes.c_int32), ('skip', ctypes.c_int32)]
+
+
+def scatter_episodes(engine, staged, jobs):
+    """Append stored episodes to rings with one kernel launch.
+
+    staged : f32 [E, T, 20] device tensor the rollout kernel wrote (`transitions`)
+    jobs   : list of (ring: DeviceReplay, episode index, n_steps, cost_only, n_rows) in the order the reference would
+             have add()-ed them (agent.py:101-112: shared buffer, agent.buffer, agent.critical_buffer per step; rings
+             are independent, so per-ring order is what matters); n_rows = n_steps, or the episode's cost-step count
+             for cost_only jobs (known from the rollout's `cost_steps`)."""
+    from . import _capi
+    if not jobs:
+        return
+    arr = (_Job * len(jobs))()
+    for j, (ring, e, n, cost_only, n_rows) in enumerate(jobs):
+        first, skip = ring._advance(int(n_rows))
+        arr[j] = _Job(ring.rows.data_ptr(), ring.capacity, first, int(e), int(n), int(bool(cost_only)), int(skip))
+    dev = staged.device
+    buf = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _capi.check(engine.lib.serl_replay_scatter(engine.ctx, staged.data_ptr(), int(staged.shape[1]), buf.data_ptr(), len(jobs), stream),
+                'serl_replay_scatter')
+    staged.record_stream(torch.cuda.current_stream(dev)) if hasattr(staged, 'record_stream') else None

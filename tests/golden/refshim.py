@@ -84,6 +84,7 @@ def install(use_oracle_dynamics=False):
         sys.modules[name] = m
         pkg = importlib.import_module('envs.%s' % build)
         pkg._citation = m
+    sys.path[:] = [str(p) for p in sys.path]      # (the reference's envs/__init__.py appends pathlib objects)
 
 
 def make_env(mode='nominal', t_max=80):

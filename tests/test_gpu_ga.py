@@ -1,0 +1,180 @@
+"""GPU tests of the SSNE operators that need the actor itself and of the device replay rings, against golden vectors from the
+REFERENCE'S OWN mod_neuro_evo.py / genetic_agent.py / replay_memory.py (tests/golden/make_proximal_golden.py)."""
+import random, types
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+MAG, MBS = 0.0247682869654, 86
+
+
+def _spec(tag):
+    import serl_amd
+    return serl_amd.NetSpec(7, 3, 32, 3, 'tanh') if tag == 'serl50' else serl_amd.NetSpec(7, 3, 96, 3, 'relu')
+
+
+def _rings(engine, g, key):
+    """buffer / critical buffer of a golden agent as device rings, filled in the reference's order"""
+    from serl_amd.replay import DeviceReplay
+    rows = torch.from_numpy(g['buf_' + key])
+    buf, crit = DeviceReplay(10_000, engine.device, engine), DeviceReplay(10_000, engine.device, engine)
+    buf.append_rows(rows)
+    crit.append_rows(rows[torch.from_numpy(g['crit_' + key].astype(np.int64))])
+    return buf, crit
+
+
+def _genome(row, spec):
+    return np.concatenate([row[o:o + n] for o, n in spec.genome_segments()])
+
+
+@pytest.mark.parametrize('tag,idx,ops', [('serl50', 18, ('prox', 'safe')), ('serl50', 0, ('prox', 'safe')), ('td3', 0, ('prox',))])
+def test_proximal_and_safe_mutation_vs_reference(engine, golden, tag, idx, ops):
+    """SSNE.proximal_mutate / safe_mutate (mod_neuro_evo.py:183-223, 254-298): seeded python `random` (batch) and torch
+    (perturbation) -> the genome the reference's own operator left.  Tolerance: the sensitivity is an f32 sum over 86 x 3
+    backward passes in another order than autograd's (rtol 2e-5 on scaling); the update divides a N(0, 0.025) draw by a
+    scaling >= 0.01, so the new weights agree to 2e-5 absolute / 2e-5 relative."""
+    from serl_amd import ga
+    g = golden('proximal')
+    key = '%s_%d' % (tag, idx)
+    spec = _spec(tag)
+    w0 = golden('actors')[tag][[idx]]
+    buf, crit = _rings(engine, g, key)
+    for op in ops:
+        seed = int(g['%s_seed_%s' % (op, key)])
+        w = torch.from_numpy(np.ascontiguousarray(w0)).to(engine.device)
+        if w.shape[1] % 4:
+            w = torch.nn.functional.pad(w, (0, (-w.shape[1]) % 4)).contiguous()
+        random.seed(seed); torch.manual_seed(seed)
+        if op == 'prox':
+            sc = ga.proximal_mutate(engine, w, 0, spec, MAG, buf, MBS)
+        else:
+            sc = ga.safe_mutate(engine, w, 0, spec, MAG, buf, crit, MBS)
+        torch.cuda.synchronize()
+        # the batch is the one the reference sampled
+        random.seed(seed)
+        src = buf if op == 'prox' else crit
+        np.testing.assert_array_equal(np.asarray(src.sample_slots(MBS)), g['%s_pick_%s' % (op, key)])
+        if '%s_scaling_%s' % (op, key) in g.files:
+            np.testing.assert_allclose(sc.cpu().numpy(), g['%s_scaling_%s' % (op, key)], rtol=2e-5, atol=1e-7)
+        got = _genome(w[0].cpu().numpy(), spec)
+        want = g['%s_%s' % (op, key)]
+        assert np.abs(want - _genome(w0[0], spec)).max() > 1e-3, 'the golden must have moved the weights'
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+        # biases / norms are not part of the genome and stay untouched
+        mask = np.ones(spec.param_count, bool)
+        for o, n in spec.genome_segments():
+            mask[o:o + n] = False
+        np.testing.assert_array_equal(w[0].cpu().numpy()[:spec.param_count][mask], w0[0][mask])
+
+
+def test_sort_groups_by_distance_vs_reference(engine, golden):
+    """SSNE.sort_groups_by_distance (mod_neuro_evo.py:411-445) over four shipped actors with reference-filled buffers:
+    pairs, order and distances of the reference's own call under the same `random` seed."""
+    from serl_amd import ga
+    g = golden('proximal')
+    spec = _spec('serl50')
+    w = torch.from_numpy(golden('actors')['serl50'][[18, 0, 7, 33]]).to(engine.device)
+    w = torch.nn.functional.pad(w, (0, (-w.shape[1]) % 4)).contiguous()
+    bufs = [_rings(engine, g, 'serl50_%d' % i)[0] for i in (18, 0, 7, 33)]
+    random.seed(int(g['dist_seed']))
+    groups = ga.sort_groups_by_distance(engine, w, [0, 1, 2, 3], bufs, spec)
+    want = g['dist_groups']
+    assert [(a, b) for a, b, _ in groups] == [(int(a), int(b)) for a, b, _ in want]
+    np.testing.assert_allclose([d for _, _, d in groups], want[:, 2], rtol=1e-5)
+
+
+def test_replay_scatter_kernel(engine):
+    """serl_replay_scatter: whole episodes appended to rings in step order, wrap-around, cost-flagged rows compacted, an
+    episode longer than the ring leaves its tail -- against n sequential add() calls emulated in numpy."""
+    from serl_amd.replay import DeviceReplay, scatter_episodes
+    rs = np.random.RandomState(0)
+    E, T = 5, 700
+    staged = rs.randn(E, T, 20).astype(np.float32)
+    staged[..., 19] = (rs.rand(E, T) < 0.3)
+    lens = [700, 333, 1, 512, 64]
+    dev = engine.device
+    st = torch.from_numpy(staged).to(dev)
+    shared, small = DeviceReplay(1500, dev, engine), DeviceReplay(300, dev, engine)
+    own = [DeviceReplay(1000, dev, engine) for _ in range(E)]
+    crit = [DeviceReplay(100, dev, engine) for _ in range(E)]
+
+    def emulate(cap, rows_list, pos=0, size=0, mem=None):
+        mem = np.zeros((cap, 20), np.float32) if mem is None else mem
+        for rows in rows_list:
+            for r in rows:
+                mem[pos] = r; pos = (pos + 1) % cap; size = min(cap, size + 1)
+        return mem, pos, size
+    for rnd in range(2):          # second round: rings already partly filled / wrapped
+        jobs = []
+        for e in range(E):
+            n = lens[e]
+            nc = int(staged[e, :n, 19].sum())
+            jobs += [(shared, e, n, False, n), (small, e, n, False, n), (own[e], e, n, False, n), (crit[e], e, n, True, nc)]
+        scatter_episodes(engine, st, jobs)
+        torch.cuda.synchronize()
+    eps = [staged[e, :lens[e]] for e in range(E)]
+    for ring, lists in [(shared, eps * 2), (small, eps * 2)] + [(own[e], [eps[e]] * 2) for e in range(E)] + \
+                       [(crit[e], [eps[e][eps[e][:, 19] != 0]] * 2) for e in range(E)]:
+        mem, pos, size = emulate(ring.capacity, lists)
+        assert (ring.position, len(ring)) == (pos, size)
+        np.testing.assert_array_equal(ring.rows.cpu().numpy()[:size], mem[:size])
+
+
+class _Critic(torch.nn.Module):
+    """stand-in for TD3's twin critic (base/core/td3.py:17-85): two small MLPs over (state, action)"""
+
+    def __init__(self):
+        super().__init__()
+        self.q1 = torch.nn.Sequential(torch.nn.Linear(10, 32), torch.nn.ELU(), torch.nn.Linear(32, 1))
+        self.q2 = torch.nn.Sequential(torch.nn.Linear(10, 32), torch.nn.ELU(), torch.nn.Linear(32, 1))
+
+    def forward(self, s, a):
+        x = torch.cat([s, a], -1)
+        return self.q1(x), self.q2(x)
+
+
+def test_default_config_epoch_runs_on_device(engine, golden):
+    """The reference's default SSNE configuration (base/parameters.py:110-115: proximal mutation, distillation crossover,
+    distance-sorted parent groups) on a device-resident population of 8 with reference-filled rings: the operator sequence
+    is consistent, elites are copied bit for bit together with their rings, distilled children differ from both parents,
+    everything stays finite."""
+    from serl_amd import ssne
+    g = golden('proximal')
+    spec = _spec('serl50')
+    n = 8
+    w0 = golden('actors')['serl50'][:n].copy()
+    w = torch.nn.functional.pad(torch.from_numpy(w0), (0, 1)).contiguous().to(engine.device)
+    keys = ['serl50_18', 'serl50_0', 'serl50_7', 'serl50_33']
+    rings = [_rings(engine, g, keys[i % 4]) for i in range(n)]
+    bufs, crits = [r[0] for r in rings], [r[1] for r in rings]
+    args = types.SimpleNamespace(pop_size=n, elite_fraction=0.25, mutation_prob=0.9, mutation_mag=MAG, mut_type='proximal',
+                                 distil_crossover=True, distil_type='distance', crossover_prob=0.0, mutation_batch_size=MBS,
+                                 individual_bs=2_000)
+    torch.manual_seed(0)
+    critic = _Critic().to(engine.device)
+    fit = np.random.default_rng(2).normal(-150, 50, n)
+    rec = []
+    random.seed(3); np.random.seed(3); torch.manual_seed(3)
+    s = ssne.SSNE(args, engine, spec, critic=critic, record=rec)
+    elite_slot = s.epoch(w, fit, buffers=bufs, critical=crits)
+    torch.cuda.synchronize()
+    out = w.cpu().numpy()[:, :spec.param_count]
+    assert np.isfinite(out).all()
+    kinds = [r[0] for r in rec]
+    assert kinds.count(3) >= 1 and kinds.count(2) >= 1 and kinds[0] == 0
+    best = int(np.argmax(fit))
+    assert rec[0] == (0, best, elite_slot)
+    mutated = {r[1] for r in rec if r[0] == 2}
+    if elite_slot not in mutated:
+        np.testing.assert_array_equal(out[elite_slot], w0[best])
+    assert len(bufs[elite_slot]) == len(bufs[best])
+    np.testing.assert_array_equal(bufs[elite_slot].rows[:50].cpu().numpy(), bufs[best].rows[:50].cpu().numpy())
+    # a distilled child: cloned into an unselected slot right after its distillation
+    k = kinds.index(3)
+    first, second, slot = rec[k][1], rec[k][2], rec[k + 1][2]
+    assert rec[k + 1][0] == 0 and rec[k + 1][1] == -1
+    if slot not in mutated:
+        assert np.abs(out[slot] - w0[second]).max() > 1e-4 and np.abs(out[slot] - w0[first]).max() > 1e-4
+    assert len(bufs[slot]) == min(2000, 2 * min(1000, len(bufs[first])))
+    assert len(crits[slot]) == 0
