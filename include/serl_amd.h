@@ -66,6 +66,24 @@ typedef struct serl_fault_row {
   double elev_gain, elev_clip, ail_clip, rudder_jam_on, rudder_jam, pad0, pad1, pad2;
 } serl_fault_row;
 
+/* A reference signal of one episode as PARAMETERS instead of a table: theta and phi are
+ * `signals.SmoothedStepSequence(times, amplitudes, smooth_width)` objects (call sites envs/phlabenv.py:303-345,
+ * base/evaluate.py:173-180, base/evaluation_utils.py:51), beta is Const(0): at the env's accumulated time t
+ *   i = last index with t >= times[i] (none: the channel is 0);  prev = i ? amps[i-1] : 0;  s = min((t - times[i]) / w, 1)
+ *   v = prev + (amps[i] - prev) * (1 - cos(pi * s)) / 2                                      [degrees]
+ *   ref = (pi/180) * [v_theta + (0 <= t <= t_max ? trim_deg : 0),  v_phi,  0]
+ * cos(pi s) is evaluated with + - * only (det_cospi: reflection to [0, 1/4], Taylor polynomials of cos / sin through
+ * x^20 / x^21 in Horner form) so that the kernels and the CPU oracle agree bit for bit; against a libm cosine the
+ * reference value differs by <= 2 ulp.  Per env step this replaces the 24 B read of ref[k] by arithmetic. */
+#define SERL_REF_MAX_STEPS 8
+typedef struct serl_ref_spec {
+  int32_t n_theta, n_phi;            /* number of steps of each channel, <= SERL_REF_MAX_STEPS */
+  double w_theta, w_phi;             /* smooth widths, seconds */
+  double trim_deg;                   /* theta trim (envs/phlabenv.py:202,319-320,344) */
+  double t_theta[SERL_REF_MAX_STEPS], a_theta[SERL_REF_MAX_STEPS];
+  double t_phi[SERL_REF_MAX_STEPS], a_phi[SERL_REF_MAX_STEPS];
+} serl_ref_spec;
+
 typedef struct serl_rollout_desc {
   /* -- actor network (base/core/genetic_agent.py:69-102).  f32 arithmetic, part of this ABI (the HIP kernels and the CPU
    *    oracle implement it bit for bit): a dot product is four interleaved partial sums p[j & 3] = fmaf(w[j], h[j],
@@ -129,6 +147,9 @@ typedef struct serl_rollout_desc {
   double *rewards;                  /* reward per step:      [n_episodes][max_steps] */
   float *transitions;               /* (obs7,a3,next_obs7,r,done,cost) f32 x20 per step:
                                        [n_episodes][max_steps][20]  (base/core/agent.py:101-112) */
+  /* -- reference generation in the kernel (NULL = table mode: `ref` is read) */
+  const serl_ref_spec *ref_spec;    /* [n_episodes] (ref_spec_stride 1) or one shared spec (stride 0); `ref` may be NULL */
+  int64_t ref_spec_stride;
 } serl_rollout_desc;
 
 int serl_abi_version(void);

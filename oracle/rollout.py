@@ -24,7 +24,18 @@ class RolloutDesc(ctypes.Structure):
                 ('max_steps', ctypes.c_int32), ('lanes_per_wave', ctypes.c_int32),
                 ('concurrent_episodes', ctypes.c_int32), ('pad_', ctypes.c_int32),
                 ('fitness', _D), ('length_steps', _I), ('length_t', _D), ('cost_steps', _I),
-                ('actions', _D), ('states', _D), ('rewards', _D), ('transitions', _F)]
+                ('actions', _D), ('states', _D), ('rewards', _D), ('transitions', _F),
+                ('ref_spec', ctypes.c_void_p), ('ref_spec_stride', ctypes.c_int64)]
+
+
+def _n_steps_for(t_max, dt=0.01):
+    """steps of a full-length episode: first k with the accumulated t_k >= t_max, inclusive (envs/phlabenv.py:391-399,473)"""
+    acc, k = 0.0, 0
+    while True:
+        k += 1
+        if acc >= t_max:
+            return k
+        acc += dt
 
 
 def param_count(S, H, L, A):
@@ -67,9 +78,16 @@ def rollout(weights, net, member_of_episode, ref, *, build='h2000_v90', faults=N
     weights = np.ascontiguousarray(weights, dtype=np.float32)
     moe = np.ascontiguousarray(member_of_episode, dtype=np.int32)
     n_ep = len(moe)
-    ref = np.ascontiguousarray(ref, dtype=np.float64)
-    shared = ref.ndim == 2
-    T = ref.shape[-2]
+    spec = None
+    if isinstance(ref, np.ndarray) and ref.dtype.names:         # serl_ref_spec rows: the reference is generated, not read
+        spec = np.ascontiguousarray(ref)
+        assert spec.dtype.itemsize == 288 and len(spec) in (1, n_ep)
+        T = _n_steps_for(t_max)
+        ref, shared = np.zeros((1, 3)), True
+    else:
+        ref = np.ascontiguousarray(ref, dtype=np.float64)
+        shared = ref.ndim == 2
+        T = ref.shape[-2]
     P = param_count(net['state_dim'], net['hidden'], net['num_layers'], net['action_dim'])
     assert weights.shape[1] >= P
     out = dict(fitness=np.zeros(n_ep), length_steps=np.zeros(n_ep, np.int32), length_t=np.zeros(n_ep),
@@ -81,6 +99,10 @@ def rollout(weights, net, member_of_episode, ref, *, build='h2000_v90', faults=N
                     ref=ref.ctypes.data_as(_D), ref_stride=0 if shared else T * 3, t_max=float(t_max),
                     max_steps=T, lanes_per_wave=0)
     keep = [weights, moe, ref]
+    if spec is not None:
+        d.ref = None
+        d.ref_spec, d.ref_spec_stride = spec.ctypes.data, (0 if len(spec) == 1 else 1)
+        keep.append(spec)
     if faults is not None:
         if len(faults) and isinstance(faults[0], str):
             faults = [FAULT_ROWS[f] for f in faults]

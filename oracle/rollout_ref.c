@@ -85,6 +85,47 @@ static DET_FN float det_expm1f_neg(float xf)     /* x <= 0 (the ELU branch) */
   return (float)(k == 0 ? q : DET_POW2(k) * (q + 1.0) - 1.0);
 }
 
+/* cos(pi s), 0 <= s <= 1 (include/serl_amd.h, serl_ref_spec) -- the same operations as the HIP kernels' det_cospi */
+static DET_FN double det_cospi(double s)
+{
+  const double PI = 3.14159265358979323846;
+  const int neg = s > 0.5;
+  const double r = neg ? 1.0 - s : s;
+  const int use_cos = r <= 0.25;
+  const double x = use_cos ? PI * r : PI * (0.5 - r);
+  const double x2 = x * x;
+  static const double C[11] = {1.0, -0.5, 0.041666666666666664, -0.001388888888888889, 2.48015873015873e-05, -2.755731922398589e-07,
+                               2.08767569878681e-09, -1.1470745597729725e-11, 4.779477332387385e-14, -1.5619206968586225e-16,
+                               4.110317623312165e-19};
+  static const double S[11] = {1.0, -0.16666666666666666, 0.008333333333333333, -0.0001984126984126984, 2.7557319223985893e-06,
+                               -2.505210838544172e-08, 1.6059043836821613e-10, -7.647163731819816e-13, 2.8114572543455206e-15,
+                               -8.22063524662433e-18, 1.9572941063391263e-20};
+  double pc = C[10], ps = S[10];
+  for (int k = 9; k >= 0; --k) { pc = C[k] + x2 * pc; ps = S[k] + x2 * ps; }
+  const double c = use_cos ? pc : x * ps;
+  return neg ? -c : c;
+}
+
+static double ref_channel(const double *tt, const double *aa, int n, double w, double t)
+{
+  double ti = 0.0, a = 0.0, prev = 0.0;
+  int on = 0;
+  for (int i = 0; i < n && i < SERL_REF_MAX_STEPS; ++i)
+    if (t >= tt[i]) { prev = on ? a : 0.0; ti = tt[i]; a = aa[i]; on = 1; }
+  if (!on) return 0.0;
+  double s = (t - ti) / w;
+  s = s < 1.0 ? s : 1.0;
+  return prev + (a - prev) * (1.0 - det_cospi(s)) / 2.0;
+}
+
+static void ref_generate(const serl_ref_spec *r, double t, double t_max, double *rk)
+{
+  const double D2R = 3.14159265358979323846 / 180.0;
+  const double th = ref_channel(r->t_theta, r->a_theta, r->n_theta, r->w_theta, t) + ((0.0 <= t && t <= t_max) ? r->trim_deg : 0.0);
+  const double ph = ref_channel(r->t_phi, r->a_phi, r->n_phi, r->w_phi, t);
+  rk[0] = th * D2R; rk[1] = ph * D2R; rk[2] = 0.0 * D2R;
+}
+
 static float act_f(float v, int act)
 {
   switch (act) {
@@ -170,7 +211,8 @@ static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, in
   const serl_fault_row nominal = {1.0, INFINITY, INFINITY, 0.0, 0.0, 0, 0, 0};
   const serl_fault_row *f = d->faults ? &d->faults[e] : &nominal;
   const float *w = d->weights + (size_t)d->member_of_episode[e] * d->weight_stride;
-  const double *ref = d->ref + (size_t)e * d->ref_stride;
+  const double *ref = d->ref ? d->ref + (size_t)e * d->ref_stride : NULL;
+  const serl_ref_spec *rspec = d->ref_spec ? d->ref_spec + (size_t)e * d->ref_spec_stride : NULL;
   const double *snoise = NULL;                         /* this episode's row of pre-drawn sensor noise, if any */
   if (d->sensor_noise) {
     const int sr = d->sensor_row ? d->sensor_row[e] : e;
@@ -226,7 +268,9 @@ static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, in
     cit_step(I, cmd, x);
     if (snoise) add_sensor_noise(x, snoise + (size_t)(k + 1) * 7);
     /* reward (phlabenv.py:347-367): reference at the pre-increment time */
-    const double *rk = ref + (size_t)k * 3;
+    double rk[3];
+    if (rspec) ref_generate(rspec, t, d->t_max, rk);
+    else { rk[0] = ref[(size_t)k * 3]; rk[1] = ref[(size_t)k * 3 + 1]; rk[2] = ref[(size_t)k * 3 + 2]; }
     err[0] = rk[0] - x[7]; err[1] = rk[1] - x[6]; err[2] = rk[2] - x[5];
     double rsum = 0.0;
     for (int i = 0; i < 3; ++i) rsum = rsum + fabs(clipd(scaler[i] * err[i], -1.0, 1.0));

@@ -11,7 +11,8 @@ and the host-side mirror of the reference interface for this path:
   validate_pop                 base/evaluate.py:59-150,236-256 (-eval_pop: nMAE / smoothness / champion)
   reference signals            `signals` call sites, envs/phlabenv.py:303-349 (refsignals.py)
   calc_smoothness / calc_nMAE  base/core/utils.py:39-58,82-120      (metrics.py)
-  SSNE tensor ops              base/core/mod_neuro_evo.py           (ga.py)
+  SSNE operators and epoch     base/core/mod_neuro_evo.py           (ga.py, ssne.py, distill.py)
+  DeviceReplay rings           base/core/replay_memory.py:12-103, agent.py:101-112   (replay.py)
   member sharding + RCCL all-gather of fitness                      (distributed.py)
 
 The HIP extension is mandatory: importing the evaluator on a machine without the built
@@ -21,8 +22,10 @@ from .actor import Actor, GeneticAgent, pack_actor, pack_population, NetSpec
 from .episode import Episode
 from .evaluator import RolloutEngine, evaluate_pop, validate_pop, make_evaluate, PopResult
 from .generation import evaluate_generation, validate_actor, GenerationResult
-from . import refsignals, metrics, ga, distributed, builds
+from .replay import DeviceReplay
+from .ssne import SSNE
+from . import refsignals, metrics, ga, distributed, builds, replay, ssne
 
 __all__ = ['Actor', 'GeneticAgent', 'pack_actor', 'pack_population', 'NetSpec', 'Episode', 'RolloutEngine',
            'evaluate_pop', 'validate_pop', 'make_evaluate', 'PopResult', 'evaluate_generation', 'validate_actor',
-           'GenerationResult', 'refsignals', 'metrics', 'ga', 'distributed', 'builds']
+           'GenerationResult', 'DeviceReplay', 'SSNE', 'replay', 'ssne', 'refsignals', 'metrics', 'ga', 'distributed', 'builds']

@@ -29,7 +29,8 @@ class RolloutDesc(ctypes.Structure):
                 ('max_steps', ctypes.c_int32), ('lanes_per_wave', ctypes.c_int32),
                 ('concurrent_episodes', ctypes.c_int32), ('pad_', ctypes.c_int32),
                 ('fitness', VP), ('length_steps', VP), ('length_t', VP), ('cost_steps', VP),
-                ('actions', VP), ('states', VP), ('rewards', VP), ('transitions', VP)]
+                ('actions', VP), ('states', VP), ('rewards', VP), ('transitions', VP),
+                ('ref_spec', VP), ('ref_spec_stride', ctypes.c_int64)]
 
 
 _lib = None

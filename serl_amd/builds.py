@@ -75,6 +75,41 @@ def sensor_noise_table(n_steps, rng=np.random):
     t[:, 5:7] = 4.0 * 10**(-3) + 3.2 * 10**(-5) * z[:, 5:7]
     return t
 
+def sensor_terms(z):
+    """the wrapper's expressions (envs/noise/citation.py:71-82) applied to standard-normal draws z [.., 7]"""
+    t = np.empty_like(z)
+    t[..., 0:3] = 3.0 * 10**(-5) + 6.3 * 10**(-4) * z[..., 0:3]
+    t[..., 3] = 4.0 * 10**(-10) * z[..., 3]
+    t[..., 4] = 1.8 * 10**(-3) + 2.7 * 10**(-4) * z[..., 4]
+    t[..., 5:7] = 4.0 * 10**(-3) + 3.2 * 10**(-5) * z[..., 5:7]
+    return t
+
+
+def draw_episode_noise(n_steps, action, sensor, rng=np.random):
+    """The np.random draws of ONE sequential reference episode, pre-drawn in the reference's interleaved order:
+    reset() -> step(): sensor model 7 draws (if the mode has one); then per env step: exploration noise randn(3)
+    (base/core/agent.py:91, if enabled) followed by the sensor model's 7 draws inside env.step().
+    -> (z_action [n_steps, 3] standard normals or None, sensor table [n_steps + 1, 7] or None, resync)
+    where resync(n) rewinds the generator and re-draws exactly what an episode of n steps consumes, so that a seeded run
+    leaves np.random where the reference's run leaves it (an episode that ends early draws less)."""
+    per = (3 if action else 0) + (7 if sensor else 0)
+    head = 7 if sensor else 0
+    if per == 0:
+        return None, None, (lambda n: None)
+    state = rng.get_state()
+    z = rng.randn(head + n_steps * per)
+    body = z[head:].reshape(n_steps, per)
+    za = body[:, :3].copy() if action else None
+    sn = None
+    if sensor:
+        sn = sensor_terms(np.concatenate([z[:7][None], body[:, per - 7:]], 0))
+
+    def resync(n):
+        rng.set_state(state)
+        rng.randn(head + int(n) * per)
+    return za, sn, resync
+
+
 _index = None
 _cache = {}
 

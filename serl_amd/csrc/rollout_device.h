@@ -82,6 +82,66 @@ static DET_FN float det_expm1f_neg(float xf)     /* x <= 0 (the ELU branch) */
   return (float)(k == 0 ? q : DET_POW2(k) * (q + 1.0) - 1.0);
 }
 
+/* cos(pi * s), 0 <= s <= 1, with + - * only (include/serl_amd.h, serl_ref_spec): cos(pi s) = -cos(pi (1 - s)) for s > 1/2,
+ * then cos(pi s) for s <= 1/4 and sin(pi (1/2 - s)) beyond, both arguments in [0, pi/4], Taylor series in Horner form. */
+static DET_FN double det_cospi(double s)
+{
+  const double PI = 3.14159265358979323846;
+  const bool neg = s > 0.5;
+  const double r = neg ? 1.0 - s : s;
+  const bool use_cos = r <= 0.25;
+  const double x = use_cos ? PI * r : PI * (0.5 - r);
+  const double x2 = x * x;
+  // cos: sum (-1)^k x^2k / (2k)!, k = 0..10;  sin: x * sum (-1)^k x^2k / (2k+1)!, k = 0..10
+  double pc = 4.110317623312165e-19;                     // 1/20!
+  pc = -1.5619206968586225e-16 + x2 * pc;                // -1/18!
+  pc = 4.779477332387385e-14 + x2 * pc;                  // 1/16!
+  pc = -1.1470745597729725e-11 + x2 * pc;                // -1/14!
+  pc = 2.08767569878681e-09 + x2 * pc;                   // 1/12!
+  pc = -2.755731922398589e-07 + x2 * pc;                 // -1/10!
+  pc = 2.48015873015873e-05 + x2 * pc;                   // 1/8!
+  pc = -0.001388888888888889 + x2 * pc;                  // -1/6!
+  pc = 0.041666666666666664 + x2 * pc;                   // 1/4!
+  pc = -0.5 + x2 * pc;
+  pc = 1.0 + x2 * pc;
+  double ps = 1.9572941063391263e-20;                    // 1/21!
+  ps = -8.22063524662433e-18 + x2 * ps;                  // -1/19!
+  ps = 2.8114572543455206e-15 + x2 * ps;                 // 1/17!
+  ps = -7.647163731819816e-13 + x2 * ps;                 // -1/15!
+  ps = 1.6059043836821613e-10 + x2 * ps;                 // 1/13!
+  ps = -2.505210838544172e-08 + x2 * ps;                 // -1/11!
+  ps = 2.7557319223985893e-06 + x2 * ps;                 // 1/9!
+  ps = -0.0001984126984126984 + x2 * ps;                 // -1/7!
+  ps = 0.008333333333333333 + x2 * ps;                   // 1/5!
+  ps = -0.16666666666666666 + x2 * ps;                   // -1/3!
+  ps = 1.0 + x2 * ps;
+  const double c = use_cos ? pc : x * ps;
+  return neg ? -c : c;
+}
+
+/* one channel of serl_ref_spec at time t, degrees */
+static DET_FN double serl_ref_channel(const double *tt, const double *aa, int n, double w, double t)
+{
+  double ti = 0.0, a = 0.0, prev = 0.0;
+  bool on = false;
+  for (int i = 0; i < SERL_REF_MAX_STEPS; ++i) {
+    if (i < n && t >= tt[i]) { prev = on ? a : 0.0; ti = tt[i]; a = aa[i]; on = true; }
+  }
+  if (!on) return 0.0;
+  double s = (t - ti) / w;
+  s = s < 1.0 ? s : 1.0;
+  return prev + (a - prev) * (1.0 - det_cospi(s)) / 2.0;
+}
+
+/* the reference sample of env time t (radians): table row k or generated from the episode's spec */
+static DET_FN void serl_ref_generate(const serl_ref_spec *r, double t, double t_max, double &r0, double &r1, double &r2)
+{
+  const double D2R = 3.14159265358979323846 / 180.0;
+  const double th = serl_ref_channel(r->t_theta, r->a_theta, r->n_theta, r->w_theta, t) + ((0.0 <= t && t <= t_max) ? r->trim_deg : 0.0);
+  const double ph = serl_ref_channel(r->t_phi, r->a_phi, r->n_phi, r->w_phi, t);
+  r0 = th * D2R; r1 = ph * D2R; r2 = 0.0 * D2R;
+}
+
 static __device__ __forceinline__ float serl_act(float v, int act)
 {
   if (act == SERL_ACT_TANH) return det_tanhf(v);

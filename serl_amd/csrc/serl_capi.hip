@@ -195,7 +195,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   if (d->build_slot < 0 || d->build_slot >= SERL_MAX_SLOTS || !c->slots[d->build_slot].loaded)
     return fail(SERL_E_INVALID, "serl_rollout: build slot not loaded");
   if (d->n_episodes <= 0) return fail(SERL_E_INVALID, "serl_rollout: n_episodes <= 0");
-  if (!d->weights || !d->member_of_episode || !d->ref || !d->fitness || !d->length_steps || !d->length_t || !d->cost_steps)
+  if (!d->weights || !d->member_of_episode || (!d->ref && !d->ref_spec) || !d->fitness || !d->length_steps || !d->length_t || !d->cost_steps)
     return fail(SERL_E_INVALID, "serl_rollout: required device pointer is NULL");
   if (d->state_dim != 7 || d->action_dim != 3)
     return fail(SERL_E_UNSUPPORTED, "serl_rollout: only the PH-LAB attitude task (state_dim 7, action_dim 3) is compiled in");

@@ -101,10 +101,16 @@ class RolloutEngine:
             w = pad_rows(w)
         moe = torch.as_tensor(np.asarray(member_of_episode), dtype=torch.int32).to(dev).contiguous()
         E = moe.numel()
-        ref_t = torch.as_tensor(ref, dtype=torch.float64).to(dev).contiguous()
-        shared = ref_t.dim() == 2
-        T = ref_t.shape[-2]
-        assert ref_t.shape[-1] == 3 and (shared or ref_t.shape[0] == E)
+        spec_t = None
+        if isinstance(ref, np.ndarray) and ref.dtype.names:     # refsignals.ref_specs rows: generated in the kernel
+            assert ref.dtype == refsignals.REF_SPEC_DTYPE and len(ref) in (1, E)
+            spec_t = torch.from_numpy(np.ascontiguousarray(ref).view(np.uint8).reshape(len(ref), -1)).to(dev)
+            ref_t, shared, T = None, True, refsignals.n_steps_for(t_max)
+        else:
+            ref_t = torch.as_tensor(ref, dtype=torch.float64).to(dev).contiguous()
+            shared = ref_t.dim() == 2
+            T = ref_t.shape[-2]
+            assert ref_t.shape[-1] == 3 and (shared or ref_t.shape[0] == E)
         out = dict(fitness=torch.zeros(E, dtype=torch.float64, device=dev),
                    length_steps=torch.zeros(E, dtype=torch.int32, device=dev),
                    length_t=torch.zeros(E, dtype=torch.float64, device=dev),
@@ -113,12 +119,14 @@ class RolloutEngine:
                               num_layers=spec.num_layers, activation=spec.activation_id, n_members=w.shape[0],
                               weights=w.data_ptr(), weight_stride=w.stride(0), n_episodes=E,
                               build_slot=self.slot_of(build), member_of_episode=moe.data_ptr(),
-                              ref=ref_t.data_ptr(), ref_stride=0 if shared else T * 3, t_max=float(t_max),
+                              ref=0 if ref_t is None else ref_t.data_ptr(), ref_stride=0 if shared else T * 3, t_max=float(t_max),
                               max_steps=T, lanes_per_wave=int(lanes_per_wave),
                               concurrent_episodes=int(concurrent_episodes),
                               fitness=out['fitness'].data_ptr(), length_steps=out['length_steps'].data_ptr(),
                               length_t=out['length_t'].data_ptr(), cost_steps=out['cost_steps'].data_ptr())
-        keep = [w, moe, ref_t]
+        keep = [w, moe, ref_t, spec_t]
+        if spec_t is not None:
+            d.ref_spec, d.ref_spec_stride = spec_t.data_ptr(), (0 if spec_t.shape[0] == 1 else 1)
         if faults is not None:
             f = torch.as_tensor(np.asarray(faults, dtype=np.float64).reshape(E, 8)).to(dev).contiguous()
             d.faults = f.data_ptr(); keep.append(f)
@@ -214,8 +222,10 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
     actors : sequence of Actor / GeneticAgent, or a packed f32 tensor [pop, P] (then pass `spec`)
     mode   : PH-LAB mode or env name ('nominal', 'be', 'PHlab_attitude_ice', ...; envs/phlabenv.py:99-172);
              a sequence gives one mode per episode (mixed-fault sweeps: one kernel launch per dynamics build)
-    refs   : f64 [pop*num_evals, T, 3] / [num_evals, T, 3] / [T, 3] radians tables (refsignals.tabulate);
-             None = the fixed base evaluation reference for every episode
+    refs   : f64 [pop*num_evals, T, 3] / [num_evals, T, 3] / [T, 3] radians tables (refsignals.tabulate), or
+             refsignals.ref_specs rows [pop*num_evals] / [num_evals] / [1] (generated inside the kernel: no table in HBM);
+             None = the fixed base evaluation reference for every episode (the reference's training loop draws a new
+             RandomizedCosineStepSequence per reset(): pass refsignals.ref_specs(*refsignals.training_references(E, t_max)))
     tick0  : i32 [pop*num_evals] model clock each episode starts with (None = 0).  The reference's initialize()
              does not reset the model clock, so in its sequential loop episode j of a process starts at
              tick = sum over earlier episodes of (steps + 1); only the time-switched builds (cg-shift, gust) care.
@@ -233,9 +243,15 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
     moe = np.repeat(np.arange(pop, dtype=np.int32), num_evals)
     if refs is None:
         refs = refsignals.tabulate(*refsignals.base_reference(t_max), t_max)
-    refs = torch.as_tensor(refs, dtype=torch.float64)
-    if refs.dim() == 3 and refs.shape[0] == num_evals and num_evals != E:
-        refs = refs.repeat(pop, 1, 1)
+    generated = isinstance(refs, np.ndarray) and refs.dtype.names is not None      # refsignals.ref_specs rows
+    if generated:
+        if len(refs) == num_evals and num_evals != E:
+            refs = np.tile(refs, pop)
+        assert len(refs) in (1, E)
+    else:
+        refs = torch.as_tensor(refs, dtype=torch.float64)
+        if refs.dim() == 3 and refs.shape[0] == num_evals and num_evals != E:
+            refs = refs.repeat(pop, 1, 1)
     modes = [mode] * E if isinstance(mode, str) else list(mode)
     assert len(modes) == E
     resolved = [builds.resolve_mode(m) for m in modes]
@@ -245,7 +261,7 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
     err0 = None if err0 is None else np.asarray(err0, dtype=np.float64).reshape(E, 3)
     # one kernel launch per dynamics build (be/jr/sa/se share the nominal build as per-episode fault rows; cg, ice,
     # cg-shift ... are builds of their own); launches are stream-ordered and their results scattered back
-    T_ref = refs.shape[-2]
+    T_ref = refsignals.n_steps_for(t_max) if generated else refs.shape[-2]
     sensor = {e: builds.sensor_noise_table(T_ref, sensor_rng if sensor_rng is not None else np.random)
               for e in range(E) if builds.has_sensor_noise(modes[e])}
     groups = {}
@@ -274,7 +290,8 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
         side = engine.side_stream(len(parts)) if many else cur
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            o = engine.rollout(w, spec, moe[idx], refs if (whole or refs.dim() == 2) else refs[torch.as_tensor(idx)], build=b,
+            o = engine.rollout(w, spec, moe[idx], (refs if (whole or len(refs) == 1) else refs[idx]) if generated else
+                               (refs if (whole or refs.dim() == 2) else refs[torch.as_tensor(idx)]), build=b,
                                faults=faults, err0=None if err0 is None else err0[idx],
                                tick0=None if tick0 is None else tick0[idx], t_max=t_max, sensor_noise=sn, sensor_row=sr,
                                traces=want, transitions=transitions, lanes_per_wave=lanes_per_wave, sync=not many,
@@ -330,14 +347,20 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
 
 
 def validate_pop(actors, refs, *, mode='nominal', t_max=80, spec: Optional[NetSpec] = None,
-                 engine: Optional[RolloutEngine] = None):
+                 engine: Optional[RolloutEngine] = None, carry_error=False):
     """The `-eval_pop` loop of the reference (base/evaluate.py:236-256 over validate_agent :123-150 over evaluate
     :59-120) in one launch: every actor flies every reference table of `refs` (f64 [num_trails+1, T, 3] rad).
 
     As in the reference's evaluate(), the error history pairs ref(t_k) with the controlled state BEFORE step k
     (the state env.reset() / the previous step left), the action history is env.last_u before step k (zeros first),
-    nMAE = calc_nMAE(errors) and smoothness = calc_smoothness(actions).  Returns dict(nmae [R, pop], smoothness
-    [R, pop], nmae_mean / nmae_sd / sm_mean / sm_sd [pop], champion = first index of the smallest mean nMAE)."""
+    nMAE = calc_nMAE(errors) and smoothness = calc_smoothness(actions) -- both batched on the device.  Returns
+    dict(nmae [R, pop], smoothness [R, pop], nmae_mean / nmae_sd / sm_mean / sm_sd [pop] (the Stats of validate_agent),
+    champion = first index of the smallest mean nMAE, last_data [pop] lazily: data(i) -> [T, 19] of actor i's last episode).
+
+    carry_error: the reference runs all episodes on ONE global env whose reset() does not clear the tracking error
+    (envs/phlabenv.py:401-428), so obs0 of every episode but the first carries the final error of the episode before it
+    (actor-major, reference-minor order).  True reproduces that with a second launch fed the first launch's final errors
+    (the final error of an 80 s episode does not depend measurably on its own obs0: one fixed-point pass)."""
     engine = engine or default_engine()
     if spec is None:
         spec = spec_of(actors[0])
@@ -350,8 +373,19 @@ def validate_pop(actors, refs, *, mode='nominal', t_max=80, spec: Optional[NetSp
     E = pop * R
     moe = np.repeat(np.arange(pop, dtype=np.int32), R)
     build, row = builds.resolve_mode(mode)
-    out = engine.rollout(w, spec, moe, refs.repeat(pop, 1, 1), build=build,
-                         faults=None if row == builds.NOMINAL_ROW else [row] * E, t_max=t_max, traces=True)
+    ref_e = refs.to(engine.device).repeat(pop, 1, 1)
+    faults = None if row == builds.NOMINAL_ROW else [row] * E
+
+    def fly(err0):
+        return engine.rollout(w, spec, moe, ref_e, build=build, faults=faults, t_max=t_max, traces=True, err0=err0)
+    out = fly(None)
+    if carry_error:
+        n = out['length_steps'].to(torch.int64).abs()
+        last = (n - 1).clamp(min=0)
+        ar = torch.arange(E, device=engine.device)
+        fin = ref_e[ar, last] - out['states'][ar, last][:, [7, 6, 5]]          # env.error after each episode's last step
+        err0 = torch.cat([torch.zeros(1, 3, dtype=torch.float64, device=engine.device), fin[:-1]], 0)
+        out = fly(err0.cpu().numpy())
     dev = out['states'].device
     n = out['length_steps'].to(torch.int64).abs()
     data, _ = builds.load(build)
@@ -359,14 +393,20 @@ def validate_pop(actors, refs, *, mode='nominal', t_max=80, spec: Optional[NetSp
     T = refs.shape[1]
     xb = torch.cat([x0.expand(E, 1, 12), out['states'][:, :T - 1]], 1)            # env.x before step k
     ub = torch.cat([torch.zeros(E, 1, 3, dtype=torch.float64, device=dev), out['actions'][:, :T - 1]], 1)
-    ref_e = refs.to(dev).repeat(pop, 1, 1)
     err = ref_e - xb[:, :, [7, 6, 5]]
-    nm = np.array([metrics.calc_nMAE(err[e, :int(n[e])]) for e in range(E)])
+    nm = metrics.calc_nMAE_batch(err, n).cpu().numpy()
     sm = metrics.calc_smoothness(ub, n).cpu().numpy()
     nm, sm = nm.reshape(pop, R).T, sm.reshape(pop, R).T
     res = dict(nmae=nm, smoothness=sm, nmae_mean=nm.mean(0), nmae_sd=nm.std(0), sm_mean=sm.mean(0), sm_sd=sm.std(0),
                length_steps=out['length_steps'].cpu().numpy().reshape(pop, R).T, kernel_ms=engine.last_kernel_ms)
     res['champion'] = int(np.argmin(res['nmae_mean']))          # `if stats.nmae < nmae_min` keeps the first minimum
+
+    def last_data(i):
+        """data[T, 19] = (ref 3, last_u 3, x 12, reward) of actor i's LAST episode, the array validate_agent returns"""
+        e = i * R + R - 1
+        k = int(n[e])
+        return torch.cat([ref_e[e, :k], ub[e, :k], xb[e, :k], out['rewards'][e, :k, None]], 1).cpu().numpy()
+    res['last_data'] = last_data
     return res
 
 
@@ -374,7 +414,11 @@ def make_evaluate(args, *, mode='nominal', t_max=20, ref_fn=None, engine=None, r
     """-> evaluate(agent, is_action_noise, store_transition) -> Episode, the signature of
     Agent.evaluate (base/core/agent.py:63-66).  One episode per call (the batched path is evaluate_pop).
 
-    ref_fn() -> f64 [T,3] radians table for the next episode (default: base reference at t_max).
+    ref_fn() -> the next episode's reference: a f64 [T,3] radians table or one refsignals.ref_specs row.  Default (None):
+    what CitationEnv.reset() does without user_refs (envs/phlabenv.py:316-335) -- a fresh randomised step sequence per
+    episode drawn from np.random (refsignals.training_references; the `signals` class behind it is not vendored by the
+    reference: parity unpinned), theta trim = rad2deg(theta0) of the build; `ref_fn='base'` flies the fixed base
+    evaluation reference (base/evaluate.py:173-180, trim 0.22 deg) every episode.
     Transitions of stored episodes are appended to `replay_buffer`, `agent.buffer` and (cost steps)
     `agent.critical_buffer` exactly as agent.py:101-112 does; `counters` (dict) receives
     num_frames / gen_frames / num_episodes increments."""
@@ -387,33 +431,43 @@ def make_evaluate(args, *, mode='nominal', t_max=20, ref_fn=None, engine=None, r
         actor = agent.actor if hasattr(agent, 'actor') else agent
         actor.eval()
         spec = spec_of(actor)
-        ref = ref_fn() if ref_fn is not None else refsignals.tabulate(*refsignals.base_reference(t_max), t_max)
-        T = ref.shape[0]
-        noise = None
-        if is_action_noise:
-            # agent.py:90-93, drawn up-front in the same order the reference draws it per step
-            noise = np.clip(args.noise_sd * np.random.randn(T, 3), -args.noise_clip, args.noise_clip)[None]
+        if ref_fn is None:
+            th, ph = refsignals.training_references(1, t_max, np.random)
+            theta0 = float(np.asarray(builds.load(builds.resolve_mode(mode)[0])[0]['x0'])[7])
+            ref = refsignals.tabulate(th[0], ph[0], t_max, theta_trim_deg=float(np.rad2deg(theta0)))
+        elif isinstance(ref_fn, str) and ref_fn == 'base':
+            ref = refsignals.tabulate(*refsignals.base_reference(t_max), t_max)
+        else:
+            ref = ref_fn()
+        if isinstance(ref, np.ndarray) and ref.dtype.names:       # a spec row: tabulate on the host for the Episode record too
+            ref_table = refsignals.tabulate_specs(ref.reshape(-1)[:1], t_max)[0]
+        else:
+            ref_table = np.asarray(ref, dtype=np.float64)
+        T = ref_table.shape[0]
+        # agent.py:90-93 / envs/noise/citation.py:71-82: this episode's np.random draws, pre-drawn in the reference's
+        # interleaved per-step order; the generator is re-synchronised to the steps actually taken afterwards
+        za, sn, resync = builds.draw_episode_noise(T, bool(is_action_noise), builds.has_sensor_noise(mode), np.random)
+        noise = None if za is None else np.clip(args.noise_sd * za, -args.noise_clip, args.noise_clip)[None]
         build, row = builds.resolve_mode(mode)
-        # sensor model of the 'noise' / 'gust' wrappers: np.random, like the reference, one block per episode up front
-        sn = builds.sensor_noise_table(T, np.random)[None] if builds.has_sensor_noise(mode) else None
-        out = engine.rollout(pack_population([actor]), spec, [0], ref, build=build, sensor_noise=sn,
+        out = engine.rollout(pack_population([actor]), spec, [0], ref, build=build, sensor_noise=None if sn is None else sn[None],
                              faults=None if row == builds.NOMINAL_ROW else [row], err0=state['err'][None], tick0=[state['tick']],
                              action_noise=noise, t_max=t_max, traces=True, transitions=store_transition)
+        resync(abs(int(out['length_steps'][0])))
         n = int(out['length_steps'][0])
         state['tick'] += abs(n) + 1          # one step in reset() + n env steps
         actions = out['actions'][0, :n].cpu().numpy()
         rewards = out['rewards'][0, :n].cpu().numpy()
         states = out['states'][0, :n].cpu().numpy()
-        state['err'] = ref[n - 1] - states[n - 1][[7, 6, 5]]
+        state['err'] = ref_table[n - 1] - states[n - 1][[7, 6, 5]]
         if store_transition:
-            from .generation import store_transitions
-            store_transitions(out['transitions'][0, :n].cpu().numpy(), agent, replay_buffer, counters)
+            from . import replay
+            replay.store_episodes(engine, out['transitions'], [(agent, 0, n, int(out['cost_steps'][0]))], replay_buffer, counters)
         smooth = float(metrics.calc_smoothness(actions[None], [n])[0])
         fitness = float(np.sum(rewards))
         if getattr(args, 'smooth_fitness', False):
             fitness += smooth
         return Episode(fitness=fitness, smoothness=smooth, length=float(out['length_t'][0]),
-                       state_history=[] if store_transition else list(states), ref_signals=ref[n - 1],
+                       state_history=[] if store_transition else list(states), ref_signals=ref_table[n - 1],
                        actions=actions, reward_lst=list(rewards))
 
     return evaluate

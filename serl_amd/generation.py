@@ -39,25 +39,17 @@ class GenerationResult:
     kernel_ms: float
 
 
-def store_transitions(rows, agent, replay_buffer=None, counters=None):
-    """rows: f32 [n, 20] = (obs7, a3, next_obs7, r, done, cost) of ONE stored episode -> the buffers of
-    agent.py:101-112 and the counters of agent.py:111-125."""
-    rows = np.asarray(rows)
-    buf = getattr(agent, 'buffer', None)
-    crit = getattr(agent, 'critical_buffer', None)
-    for r in rows:
-        t5 = (r[0:7].astype(np.float64), r[7:10], r[10:17].astype(np.float64), float(r[17]), float(r[18]))
-        if replay_buffer is not None:
-            replay_buffer.add(*t5)
-        if buf is not None:
-            buf.add(*t5)
-        if r[19] and crit is not None:
-            crit.add(*t5)
-    if counters is not None:
-        n = len(rows)
-        counters['num_frames'] = counters.get('num_frames', 0) + n
-        counters['gen_frames'] = counters.get('gen_frames', 0) + n
-        counters['num_episodes'] = counters.get('num_episodes', 0) + 1
+def store_transitions(rows, agent, replay_buffer=None, counters=None, engine=None):
+    """rows: f32 [n, 20] = (obs7, a3, next_obs7, r, done, cost) of ONE stored episode (device tensor or array) -> the
+    buffers of agent.py:101-112 and the counters of agent.py:111-125 (see replay.store_episodes)."""
+    from . import replay
+    rows = torch.as_tensor(rows)
+    n = rows.shape[0]
+    nc = int((rows[:, 19] != 0).sum())
+    if rows.is_cuda:
+        replay.store_episodes(engine or default_engine(), rows[None].contiguous(), [(agent, 0, n, nc)], replay_buffer, counters)
+    else:                          # host rows can only feed host-side buffers (objects with add(*transition))
+        replay.store_episodes(None, rows[None], [(agent, 0, n, nc)], replay_buffer, counters)
 
 
 def _actor_of(agent):
@@ -133,18 +125,22 @@ def evaluate_generation(pop: Sequence, rl_agent=None, *, args, mode='nominal', t
                     pop_fitness=pop_fitness, champion=int(np.argmax(pop_fitness)), worst=int(np.argmin(pop_fitness)),
                     kernel_ms=engine.last_kernel_ms, actions=out['actions'][:E], states=out['states'][:E],
                     rewards=out['rewards'][:E], transitions=out.get('transitions'), episode_member=moe[:E])
+    cs = out['cost_steps'].cpu().numpy()
+    stored = []
     if store:
-        tr = out['transitions']
-        for m in range(n_pop):                              # the reference's order: member by member
+        for m in range(n_pop):                              # the reference's order: member by member (agent.py:234-241)
             e = m * ne + ne - 1
-            store_transitions(tr[e, :abs(int(ls[e]))].cpu().numpy(), pop[m], replay_buffer, counters)
+            stored.append((pop[m], e, abs(int(ls[e])), int(cs[e])))
     rl_ep = None
     if rl_agent is not None:
         e = Etot - 1
         ref_row = refs[e] if refs.dim() == 3 else refs
         rl_ep = _episode(out, e, ref_row.cpu().numpy(), sm[e], smooth_fitness)
         if store:
-            store_transitions(out['transitions'][e, :abs(int(ls[e]))].cpu().numpy(), rl_agent, replay_buffer, counters)
+            stored.append((rl_agent, e, abs(int(ls[e])), int(cs[e])))
+    if stored:
+        from . import replay
+        replay.store_episodes(engine, out['transitions'], stored, replay_buffer, counters)
     return GenerationResult(pop=res, rl_episode=rl_ep, kernel_ms=engine.last_kernel_ms)
 
 

@@ -130,3 +130,97 @@ def tabulate_batch_device(times, amps_theta, amps_phi, smooth_width, t_max, devi
     th = out[0] + theta_trim_deg * inside
     ref = torch.stack([th, out[1], torch.zeros_like(th)], dim=2)
     return ref * (np.pi / 180.0)
+
+
+# ---- references as parameters: generated inside the kernel (include/serl_amd.h: serl_ref_spec) ---------------------------
+REF_MAX_STEPS = 8
+REF_SPEC_DTYPE = np.dtype([('n_theta', np.int32), ('n_phi', np.int32), ('w_theta', np.float64), ('w_phi', np.float64),
+                           ('trim_deg', np.float64), ('t_theta', np.float64, REF_MAX_STEPS), ('a_theta', np.float64, REF_MAX_STEPS),
+                           ('t_phi', np.float64, REF_MAX_STEPS), ('a_phi', np.float64, REF_MAX_STEPS)], align=True)
+assert REF_SPEC_DTYPE.itemsize == 8 + 3 * 8 + 4 * 8 * REF_MAX_STEPS
+
+
+def ref_specs(theta, phi, theta_trim_deg=0.22):
+    """Sequences of SmoothedStepSequence objects (one pair per episode) -> structured array [E] of serl_ref_spec rows.
+    The kernel evaluates them at the env's accumulated step times instead of reading a [T, 3] table per episode."""
+    theta, phi = list(theta), list(phi)
+    assert len(theta) == len(phi)
+    out = np.zeros(len(theta), dtype=REF_SPEC_DTYPE)
+    trims = np.broadcast_to(np.asarray(theta_trim_deg, dtype=np.float64), (len(theta),))
+    for e, (th, ph) in enumerate(zip(theta, phi)):
+        for sig, nk, wk, tk, ak in ((th, 'n_theta', 'w_theta', 't_theta', 'a_theta'), (ph, 'n_phi', 'w_phi', 't_phi', 'a_phi')):
+            n = len(sig.times)
+            if n > REF_MAX_STEPS:
+                raise ValueError('a reference with %d steps does not fit serl_ref_spec (max %d): tabulate it instead' % (n, REF_MAX_STEPS))
+            out[e][nk], out[e][wk] = n, sig.w
+            out[e][tk][:n], out[e][ak][:n] = sig.times, sig.amps
+        out[e]['trim_deg'] = trims[e]
+    return out
+
+
+def det_cospi(s):
+    """cos(pi s) for 0 <= s <= 1 with the kernel's operations (vectorised; include/serl_amd.h, serl_ref_spec)"""
+    s = np.asarray(s, dtype=np.float64)
+    neg = s > 0.5
+    r = np.where(neg, 1.0 - s, s)
+    use_cos = r <= 0.25
+    x = np.where(use_cos, np.pi * r, np.pi * (0.5 - r))
+    x2 = x * x
+    C = [1.0, -0.5, 0.041666666666666664, -0.001388888888888889, 2.48015873015873e-05, -2.755731922398589e-07,
+         2.08767569878681e-09, -1.1470745597729725e-11, 4.779477332387385e-14, -1.5619206968586225e-16, 4.110317623312165e-19]
+    S = [1.0, -0.16666666666666666, 0.008333333333333333, -0.0001984126984126984, 2.7557319223985893e-06, -2.505210838544172e-08,
+         1.6059043836821613e-10, -7.647163731819816e-13, 2.8114572543455206e-15, -8.22063524662433e-18, 1.9572941063391263e-20]
+    pc, ps = np.full_like(x2, C[10]), np.full_like(x2, S[10])
+    for k in range(9, -1, -1):
+        pc = C[k] + x2 * pc
+        ps = S[k] + x2 * ps
+    c = np.where(use_cos, pc, x * ps)
+    return np.where(neg, -c, c)
+
+
+def tabulate_specs(specs, t_max, dt=0.01):
+    """The table the kernel's generator produces for `specs` (same operations, vectorised on the host): f64 [E, T, 3].
+    Differs from `tabulate` (libm cosine, the reference's own arithmetic) by at most a few ulp."""
+    n = n_steps_for(t_max, dt)
+    t = env_times(n, dt)
+    out = np.zeros((len(specs), n, 3))
+    for e, r in enumerate(specs):
+        for c, (nk, wk, tk, ak) in enumerate((('n_theta', 'w_theta', 't_theta', 'a_theta'), ('n_phi', 'w_phi', 't_phi', 'a_phi'))):
+            v = np.zeros(n)
+            ti, a, prev, on = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n, bool)
+            for i in range(int(r[nk])):
+                hit = t >= r[tk][i]
+                prev = np.where(hit, np.where(on, a, 0.0), prev)
+                ti = np.where(hit, r[tk][i], ti); a = np.where(hit, r[ak][i], a); on = on | hit
+            s = np.minimum((t - ti) / r[wk], 1.0)
+            v = np.where(on, prev + (a - prev) * (1.0 - det_cospi(np.where(on, s, 0.0))) / 2.0, 0.0)
+            if c == 0:
+                v = v + np.where((0.0 <= t) & (t <= t_max), r['trim_deg'], 0.0)
+            out[e, :, c] = v * (np.pi / 180.0)
+    return out
+
+
+# ---- training references (env.reset() without user_refs, envs/phlabenv.py:316-335) ---------------------------------------
+def randomized_cosine_steps(t_max, ampl_max, block_width, smooth_width, n_levels, vary_timings=0.0, rng=np.random):
+    """Stand-in for `signals.stochastic_signals.RandomizedCosineStepSequence` (signals==0.0.1 is not vendored by the
+    reference and not installable here: PARITY UNPINNED, SURVEY 8c -- only what the training-time state histories of
+    the reference show is reproduced: one level per block drawn from linspace(-ampl_max, ampl_max, n_levels), block
+    starts every `block_width` seconds jittered by +-vary_timings, cosine blend over `smooth_width`)."""
+    n_levels = max(int(n_levels), 2)
+    block_width = max(float(block_width), 1e-6)
+    levels = np.linspace(-ampl_max, ampl_max, n_levels)
+    times = np.arange(0.0, t_max, block_width)
+    amps = rng.choice(levels, size=len(times))
+    if vary_timings:
+        times = np.concatenate([times[:1], times[1:] + rng.uniform(-vary_timings, vary_timings, len(times) - 1)])
+    return SmoothedStepSequence(times, amps, max(float(smooth_width), 1e-6))
+
+
+def training_references(n_episodes, t_max=20, rng=np.random):
+    """What CitationEnv.reset() draws per training episode (envs/phlabenv.py:316-335): theta (+-30 deg) and phi (+-20 deg)
+    step sequences with block t_max//5, smooth t_max//6, t_max//2 levels, timing jitter t_max/500.  -> (thetas, phis)."""
+    th, ph = [], []
+    for _ in range(n_episodes):
+        th.append(randomized_cosine_steps(t_max, 30, t_max // 5, t_max // 6, t_max // 2, t_max / 500., rng))
+        ph.append(randomized_cosine_steps(t_max, 20, t_max // 5, t_max // 6, t_max // 2, t_max / 500., rng))
+    return th, ph

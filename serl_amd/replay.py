@@ -127,12 +127,56 @@ def scatter_episodes(engine, staged, jobs):
     if not jobs:
         return
     arr = (_Job * len(jobs))()
+    # rows a later job of this launch (or the tail of the same job) overwrites are never written: a row survives iff fewer
+    # than `capacity` rows follow it on its ring -- the state n sequential add() calls would leave, without write races
+    total = {}
+    for ring, e, n, cost_only, n_rows in jobs:
+        total[id(ring)] = total.get(id(ring), 0) + int(n_rows)
+    seen = {}
     for j, (ring, e, n, cost_only, n_rows) in enumerate(jobs):
-        first, skip = ring._advance(int(n_rows))
-        arr[j] = _Job(ring.rows.data_ptr(), ring.capacity, first, int(e), int(n), int(bool(cost_only)), int(skip))
+        start = seen.get(id(ring), 0)
+        seen[id(ring)] = start + int(n_rows)
+        dead = total[id(ring)] - ring.capacity - start          # ranks of this job below `dead` are overwritten later
+        first, _ = ring._advance(int(n_rows))
+        arr[j] = _Job(ring.rows.data_ptr(), ring.capacity, first, int(e), int(n), int(bool(cost_only)), int(min(max(dead, 0), int(n_rows))))
     dev = staged.device
     buf = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     _capi.check(engine.lib.serl_replay_scatter(engine.ctx, staged.data_ptr(), int(staged.shape[1]), buf.data_ptr(), len(jobs), stream),
                 'serl_replay_scatter')
-    staged.record_stream(torch.cuda.current_stream(dev)) if hasattr(staged, 'record_stream') else None
+
+
+def store_episodes(engine, staged, items, replay_buffer=None, counters=None):
+    """The buffer side of Agent.evaluate for several stored episodes at once (agent.py:101-125).
+
+    items : [(agent, episode index in `staged`, n_steps, n_cost_steps)] in the reference's order (member by member, then
+            the RL actor).  Every episode goes to `replay_buffer` (the learner's shared buffer) and to agent.buffer, its
+            cost-flagged rows to agent.critical_buffer; num_frames / gen_frames advance by the steps, num_episodes by one
+            per episode.  Buffers that are DeviceReplay rings are filled by ONE serl_replay_scatter launch; any other
+            object with the reference's `add(*transition)` is fed tuple by tuple from a host copy (compatibility with
+            the reference's list-backed ReplayMemory)."""
+    jobs, host = [], []
+    for agent, e, n, nc in items:
+        n, nc = int(n), int(nc)
+        for ring, cost_only, rows in ((replay_buffer, False, n), (getattr(agent, 'buffer', None), False, n),
+                                      (getattr(agent, 'critical_buffer', None), True, nc)):
+            if ring is None:
+                continue
+            if isinstance(ring, DeviceReplay):
+                jobs.append((ring, e, n, cost_only, rows))
+            else:
+                host.append((ring, e, n, cost_only))
+        if counters is not None:
+            counters['num_frames'] = counters.get('num_frames', 0) + n
+            counters['gen_frames'] = counters.get('gen_frames', 0) + n
+            counters['num_episodes'] = counters.get('num_episodes', 0) + 1
+    if jobs:
+        scatter_episodes(engine, staged, jobs)
+    cache = {}
+    for ring, e, n, cost_only in host:
+        if e not in cache:
+            cache[e] = staged[e, :n].cpu().numpy()
+        for r in cache[e]:
+            if cost_only and not r[19]:
+                continue
+            ring.add(r[0:7].astype(np.float64), r[7:10], r[10:17].astype(np.float64), float(r[17]), float(r[18]))

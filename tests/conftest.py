@@ -78,3 +78,32 @@ def assert_same_ranking(actual, desired, mask):
     import numpy as np
     a, d = np.asarray(actual)[mask], np.asarray(desired)[mask]
     np.testing.assert_array_equal(np.argsort(a), np.argsort(d))
+
+
+class OracleEngine:
+    """TEST INFRASTRUCTURE: an object with RolloutEngine.rollout's call shape that runs the CPU oracle instead of the HIP
+    kernel, so that the host-side adaptors (make_evaluate, store_episodes, ...) can be exercised by the CPU suite.  Never
+    part of the product: serl_amd does not know it exists."""
+
+    def __init__(self):
+        import torch
+        self.device = torch.device('cpu')
+        self.last_kernel_ms = 0.0
+
+    def rollout(self, weights, spec, member_of_episode, ref, *, build='h2000_v90', faults=None, err0=None, tick0=None,
+                action_noise=None, noise_row=None, sensor_noise=None, sensor_row=None, t_max=80.0, traces=False,
+                transitions=False, lanes_per_wave=0, sync=True, concurrent_episodes=0):
+        import numpy as np, torch
+        from oracle import rollout as R
+        net = dict(state_dim=spec.state_dim, action_dim=spec.action_dim, hidden=spec.hidden, num_layers=spec.num_layers,
+                   activation=spec.activation)
+        w = np.asarray(torch.as_tensor(weights).cpu().numpy(), dtype=np.float32)
+        o = R.rollout(w, net, np.asarray(member_of_episode), ref if isinstance(ref, np.ndarray) else np.asarray(ref), build=build,
+                      faults=faults, err0=err0, tick0=tick0, action_noise=action_noise, noise_row=noise_row,
+                      sensor_noise=sensor_noise, sensor_row=sensor_row, t_max=t_max, traces=bool(traces), transitions=transitions)
+        return {k: torch.from_numpy(np.asarray(v)) for k, v in o.items()}
+
+
+@pytest.fixture
+def oracle_engine():
+    return OracleEngine()

@@ -151,3 +151,73 @@ def test_sensor_noise_table_draw_order():
                                     1.8 * 10**(-3) + 2.7 * 10**(-4) * c, 4.0 * 10**(-3) + 3.2 * 10**(-5) * d]))
     np.testing.assert_array_equal(builds.sensor_noise_table(5, np.random.RandomState(42)), np.array(rows))
     assert builds.has_sensor_noise('PHlab_attitude_noise') and builds.has_sensor_noise('gust') and not builds.has_sensor_noise('ice')
+
+
+def test_gen_refs_draw_order_matches_reference_evaluate(golden):
+    """refsignals.gen_refs against base/evaluation_utils.py:23-55 run in evaluate.py main()'s order with its seed 7
+    (tests/golden/make_evalpop_golden.py): same amplitudes and step times for the theta and the phi reference."""
+    import numpy as np
+    from serl_amd import refsignals
+    g = golden('evalpop')
+    tt = np.linspace(0., 80, 6)
+    np.random.seed(7)
+    th = refsignals.gen_refs(80, tt, 12.0, num_trails=1)
+    ph = refsignals.gen_refs(80, tt, 10.0, num_trails=1)
+    np.testing.assert_array_equal(th[0].times, g['times'][0]); np.testing.assert_array_equal(th[0].amps, g['amps_theta'][0])
+    np.testing.assert_array_equal(ph[0].times, g['times_phi'][0]); np.testing.assert_array_equal(ph[0].amps, g['amps_phi'][0])
+    assert th[0].w == 8.0
+
+
+class _ListBuf(list):
+    def add(self, *t):
+        self.append(t)
+
+
+def run_sequence(golden, name, engine, mode):
+    """Drive serl_amd.make_evaluate through one plan of tests/golden/make_seq_golden.py and compare with what the
+    REFERENCE'S OWN Agent.evaluate produced on one env / one Agent: returns, lengths, the carried error, counters, buffer
+    fills, the stored tuples, and the position of the np.random stream afterwards."""
+    import types
+    import numpy as np, torch
+    import serl_amd
+    from serl_amd import refsignals, actor as A
+    g = golden('sequence')
+    w = golden('actors')['serl50']
+    args = types.SimpleNamespace(state_dim=7, action_dim=3, hidden_size=32, num_layers=3, activation_actor='tanh',
+                                 smooth_fitness=False, noise_sd=0.2962183114680794, noise_clip=0.5)
+    shared, counters = _ListBuf(), {}
+    ref = refsignals.tabulate(*refsignals.base_reference(20), 20)
+    evaluate = serl_amd.make_evaluate(args, mode=mode, t_max=20, ref_fn=lambda: ref, engine=engine, replay_buffer=shared,
+                                      counters=counters)
+    agents = {}
+    for idx in set(int(p[0]) for p in g[name + '_plan']):
+        ag = serl_amd.GeneticAgent(args, buffer=_ListBuf(), critical_buffer=_ListBuf())
+        A.unpack_into(ag.actor, torch.from_numpy(w[idx]))
+        agents[idx] = ag
+    np.random.seed(int(g[name + '_seed']))
+    for j, (idx, noisy, store) in enumerate(g[name + '_plan']):
+        ep = evaluate(agents[int(idx)], bool(noisy), bool(store))
+        fit, length, sm, n = g[name + '_ret'][j]
+        assert len(ep.reward_lst) == int(n) and ep.length == length, (name, j)
+        np.testing.assert_allclose(ep.fitness, fit, rtol=1e-5, err_msg='%s episode %d' % (name, j))
+        np.testing.assert_allclose(ep.smoothness, sm, rtol=2e-3)
+        assert (len(ep.state_history) == 0) == bool(store)           # agent.py:113-115: states kept for unstored episodes only
+        cn = g[name + '_counters'][j]
+        assert [counters.get('num_frames', 0), counters.get('gen_frames', 0), counters.get('num_episodes', 0)] == list(cn)
+        nb = g[name + '_nbuf'][j]
+        assert [len(shared), len(agents[int(idx)].buffer), len(agents[int(idx)].critical_buffer)] == list(nb), (name, j)
+    rows = np.stack([np.concatenate([np.ravel(np.asarray(x, np.float64)) for x in t]) for t in shared])
+    np.testing.assert_allclose(rows[:30], g[name + '_shared_head'], atol=5e-6)
+    np.testing.assert_allclose(rows[-30:], g[name + '_shared_tail'], atol=2e-4)
+    # an episode consumed exactly the reference's number of np.random draws
+    np.testing.assert_array_equal(np.random.randn(4), g[name + '_after'])
+
+
+import pytest as _pytest
+
+
+@_pytest.mark.parametrize('name,mode', [('nominal', 'nominal'), ('gust', 'gust')])
+def test_make_evaluate_sequence_vs_reference_agent_evaluate(golden, oracle_engine, name, mode):
+    """(host logic of make_evaluate on the CPU: the rollout itself is served by the oracle through tests/conftest.py's
+    OracleEngine; the GPU suite runs the same sequences through the HIP kernel)"""
+    run_sequence(golden, name, oracle_engine, mode)

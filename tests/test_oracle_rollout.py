@@ -361,3 +361,26 @@ def test_exploration_noise_and_stored_transitions_vs_reference_python(golden, na
     check_noise_case(g, name, o['fitness'][0], o['length_t'][0], o['length_steps'][0], o['cost_steps'][0], o['transitions'][0])
     np.testing.assert_allclose(calc_smoothness(o['actions'][0][:T]), float(g[name + '_smoothness']), rtol=1e-4)
     assert int(g[name + '_ret'][3]) == T and int(g[name + '_ret'][4]) == 1      # frames / episodes the reference counted
+
+
+def test_generated_references_equal_their_table():
+    """serl_ref_spec in the oracle: the generator inside the episode loop == the same arithmetic tabulated on the host
+    (bit for bit), and within 2 ulp of the libm-cosine table of the `signals` restatement that the shipped trajectories pin."""
+    from oracle import rollout as R
+    from serl_amd import refsignals as rs
+    import os
+    w = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'actors.npz'))['serl50'][[18, 0, 7]]
+    th, ph = rs.training_references(2, 20, np.random.RandomState(1))
+    th0, ph0 = rs.base_reference(20)
+    ths, phs, trims = [th0] + th, [ph0] + ph, [0.22, 0.2106, 0.2106]
+    specs = rs.ref_specs(ths, phs, trims)
+    table = rs.tabulate_specs(specs, 20)
+    libm = np.stack([rs.tabulate(a, b, 20, theta_trim_deg=t) for a, b, t in zip(ths, phs, trims)])
+    assert 0 < np.abs(table).max() and np.abs(table - libm).max() < 5e-16
+    a = R.rollout(w, NET['serl50'], [0, 1, 2], specs, t_max=20, traces=True)
+    b = R.rollout(w, NET['serl50'], [0, 1, 2], table, t_max=20, traces=True)
+    c = R.rollout(w, NET['serl50'], [0, 1, 2], libm, t_max=20)
+    np.testing.assert_array_equal(a['fitness'], b['fitness']); np.testing.assert_array_equal(a['states'], b['states'])
+    np.testing.assert_allclose(a['fitness'], c['fitness'], rtol=1e-10)
+    x = np.linspace(0, 1, 200001)
+    assert np.abs(rs.det_cospi(x) - np.cos(np.pi * x)).max() < 4e-16
