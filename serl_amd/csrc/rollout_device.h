@@ -149,6 +149,22 @@ static __device__ __forceinline__ float serl_act(float v, int act)
   return v > 0.0f ? v : 0.01f * v;
 }
 
+// Progress callback of the actor forward: called after piece `piece` of `n` (input layer, then every hidden layer /
+// weight chunk, then the output layer).  The rollout kernels whose wavefront owns a whole episode pass nothing; the team
+// kernels' ACTOR WAVEFRONT uses it to pay its share of the workgroup barriers while it works (SerlBarrierCredit).
+struct SerlNoSync { __device__ __forceinline__ void operator()(int, int) const {} };
+// The actor wavefront of a team runs beside the four wavefronts that integrate the model (rollout_team.inc); the hardware
+// barrier counts every wavefront of the workgroup, so it executes the step's `per_step` barriers too -- spread evenly
+// over the pieces of its forward pass, so that it is early at every one of them and never holds the team up.
+struct SerlBarrierCredit {
+  int done, per_step;
+  __device__ __forceinline__ void operator()(int piece, int n)
+  {
+    const int target = per_step * (piece + 1) / n;
+    while (done < target) { __builtin_amdgcn_s_barrier(); ++done; }
+  }
+};
+
 #define SERL_MAX_HIDDEN 128
 #define SERL_BLOCK 256          // launch bound: up to 4 wavefronts (one per SIMD, 512 registers each) per workgroup share one LDS copy of the tables
 
@@ -279,8 +295,9 @@ static __device__ __forceinline__ float serl_tree_sum_rt(float v0, float v1, int
 // The network is walked as one sequence of 32-column weight chunks (hidden layers, then the output layer); the
 // loads of chunk i+1 are issued before the multiply-adds of chunk i, so the L2/HBM latency of the weight rows
 // (the wavefront is alone on its SIMD: nothing else hides it) overlaps with arithmetic.
+template <class Sync>
 static __device__ void serl_actor_forward_wave(const serl_rollout_desc &dd, const float *w_generic,
-                                               const float obs[7], float act_out[3])
+                                               const float obs[7], float act_out[3], Sync &sync)
 {
   // network shape is wave-uniform: pin it to SGPRs so that shape tests are scalar branches, not exec masks
   const int H = __builtin_amdgcn_readfirstlane(dd.hidden), L = __builtin_amdgcn_readfirstlane(dd.num_layers);
@@ -326,6 +343,7 @@ static __device__ void serl_actor_forward_wave(const serl_rollout_desc &dd, cons
     h0a = serl_act(serl_dot7(b[i0], wa, obs), act);
     if (two) h0b = serl_act(serl_dot7(b[i1], wb, obs), act);
   }
+  sync(0, nchunks + 1);
   float bi0 = 0.0f, bi1 = 0.0f, gm0 = 0.0f, gm1 = 0.0f, bt0 = 0.0f, bt1 = 0.0f;
   float p0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, p1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   for (int c = 0; c < nchunks; ++c) {
@@ -359,6 +377,7 @@ static __device__ void serl_actor_forward_wave(const serl_rollout_desc &dd, cons
         for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, i);
       }
     }
+    sync(c + 1, nchunks + 1);
   }
 #undef SERL_ISSUE
 }
@@ -366,9 +385,9 @@ static __device__ void serl_actor_forward_wave(const serl_rollout_desc &dd, cons
 // Shape-specialised forward for H <= 64 (one row per lane, H a multiple of 4): every loop bound is a compile-time
 // constant, a whole weight row (H floats, dwordx4 loads) plus its bias / gamma / beta are fetched one layer ahead of
 // the arithmetic.  Same operation order as serl_actor_forward_wave (= the oracle's).
-template <int H>
+template <int H, class Sync>
 static __device__ void serl_actor_forward_small(const serl_rollout_desc &dd, const float *w_generic, const float obs[7],
-                                                float act_out[3])
+                                                float act_out[3], Sync &sync)
 {
   static_assert(H % 4 == 0 && H <= 64, "one row per lane");
   const int L = __builtin_amdgcn_readfirstlane(dd.num_layers), act = __builtin_amdgcn_readfirstlane(dd.activation);
@@ -404,6 +423,7 @@ static __device__ void serl_actor_forward_small(const serl_rollout_desc &dd, con
     h = serl_act(acc, act);
   }
   CITW_T(22);
+  sync(0, L + 2);
   for (int l = 0; l <= L; ++l) {
     float row[H];
 #pragma unroll
@@ -426,6 +446,7 @@ static __device__ void serl_actor_forward_small(const serl_rollout_desc &dd, con
       for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, i);
     }
     CITW_T(24);
+    sync(l + 1, L + 2);
   }
 }
 
@@ -477,8 +498,9 @@ static __device__ __forceinline__ void serl_stage_actor_lds(const serl_rollout_d
   for (int t = threadIdx.x; t < 3; t += blockDim.x) dst[4 * H + t] = src[3 * H + t];
 }
 
+template <class Sync>
 static __device__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const float *lw_generic, const float obs[7],
-                                              float act_out[3])
+                                              float act_out[3], Sync &sync)
 {
   constexpr int H = SERL_LDS_ACTOR_H;
   const int L = __builtin_amdgcn_readfirstlane(dd.num_layers), act = __builtin_amdgcn_readfirstlane(dd.activation);
@@ -517,6 +539,7 @@ static __device__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const
     h = serl_act(acc, act);
   }
   CITW_T(22);
+  sync(0, L + 2);
   for (int l = 0; l <= L; ++l) {
     float row[H];
 #pragma unroll
@@ -539,16 +562,37 @@ static __device__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const
       for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, i);
     }
     CITW_T(24);
+    sync(l + 1, L + 2);
   }
 }
 
+static __device__ __forceinline__ void serl_actor_forward_wave(const serl_rollout_desc &dd, const float *w, const float obs[7],
+                                                               float act_out[3])
+{
+  SerlNoSync none;
+  serl_actor_forward_wave(dd, w, obs, act_out, none);
+}
+
+template <class Sync>
+static __device__ __forceinline__ void serl_actor_forward(const serl_rollout_desc &dd, const float *w, const float obs[7],
+                                                          float act_out[3], Sync &sync)
+{
+  const int H = __builtin_amdgcn_readfirstlane(dd.hidden);
+  if (H == 32) serl_actor_forward_small<32>(dd, w, obs, act_out, sync);
+  else if (H == 64) serl_actor_forward_small<64>(dd, w, obs, act_out, sync);
+  else serl_actor_forward_wave(dd, w, obs, act_out, sync);
+}
 static __device__ __forceinline__ void serl_actor_forward(const serl_rollout_desc &dd, const float *w, const float obs[7],
                                                           float act_out[3])
 {
-  const int H = __builtin_amdgcn_readfirstlane(dd.hidden);
-  if (H == 32) serl_actor_forward_small<32>(dd, w, obs, act_out);
-  else if (H == 64) serl_actor_forward_small<64>(dd, w, obs, act_out);
-  else serl_actor_forward_wave(dd, w, obs, act_out);
+  SerlNoSync none;
+  serl_actor_forward(dd, w, obs, act_out, none);
+}
+static __device__ __forceinline__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const float *lw, const float obs[7],
+                                                              float act_out[3])
+{
+  SerlNoSync none;
+  serl_actor_forward_lds(dd, lw, obs, act_out, none);
 }
 
 static __device__ __forceinline__ double serl_clip(double v, double lo, double hi)

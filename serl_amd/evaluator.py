@@ -40,6 +40,16 @@ class PopResult:
     episode_member: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
 
 
+_engines = None
+
+
+def refresh_env():
+    """Development switches (SERL_TEAM, SERL_WAVES_PER_BLOCK, SERL_PROFILE ...) are read once per context; A/B tests that
+    flip them between calls re-read them through this."""
+    for e in list(_engines or ()):
+        e.refresh_env()
+
+
 class RolloutEngine:
     """One per process / GPU.  Not thread-safe (one HIP context, calls are stream-ordered)."""
 
@@ -57,6 +67,15 @@ class RolloutEngine:
         # queues when it is created, and streams made back to back land on different ones (measured: profiles/r01_g_mixed.md)
         self._side = [torch.cuda.Stream(self.device) for _ in range(3)]
         self.last_kernel_ms = 0.0
+        global _engines
+        if _engines is None:
+            import weakref
+            _engines = weakref.WeakSet()
+        _engines.add(self)
+
+    def refresh_env(self):
+        if getattr(self, 'ctx', None):
+            _capi.check(self.lib.serl_ctx_refresh_env(self.ctx), 'serl_ctx_refresh_env')
 
     def close(self):
         if getattr(self, 'ctx', None):
