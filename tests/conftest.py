@@ -44,24 +44,35 @@ RTOL = 1e-5          # BASELINE.json north_star: episodic return within 1e-5 rel
 def tolerances(golden):
     """Per-episode relative tolerance on the episodic return.
 
-    The reference evaluates the actor in f32 with torch's CPU kernels; any other f32 implementation (the oracle's
-    sequential sums, the HIP kernel) differs from it by an ulp here and there.  tests/golden/make_sensitivity.py
-    re-ran the REFERENCE ITSELF with its action nudged by one f32 ulp per step: for most shipped actors the return
-    moves by ~1e-8, for a few poorly trained, oscillating ones by up to 8e-3 -- the reference does not define those
-    numbers any better.  The bar stays 1e-5 everywhere except for exactly those episodes, which get 50x their own
-    measured spread.  `stable` marks episodes whose spread is below 1e-6 (ranking / champion indices are asserted
-    on those)."""
+    The bar is BASELINE.json's 1e-5 for every episode but four.  The reference evaluates the actor in f32 with torch's CPU
+    kernels; any other correct f32 implementation (the oracle's specified arithmetic, the HIP kernels) differs from it by an
+    ulp here and there.  57 of the 61 shipped actors damp that (tests/golden/make_sensitivity.py: the reference's own return
+    moves by < 1e-6 when its action is nudged by one ulp per step); SERL10 actors 3, 4, 9 and the TD3 actor amplify it --
+    actors 4 and 9 sit on a chaotic limit cycle (return -700 / -268).  For those four, tests/golden/make_ensemble_golden.py
+    re-ran THE REFERENCE ITSELF 48 times under random one-ulp perturbations of its own actor output: the returns scatter
+    like a distribution (actor 4: sd 0.4 %), which is the precision to which the reference defines the number.  An
+    implementation passes on such an episode if its return lies within 4 sd of that ensemble's mean -- expressed below as a
+    relative tolerance around the un-perturbed reference value.  `stable` marks the other episodes (ranking / champion
+    indices are asserted on those)."""
     import numpy as np
-    sens = golden('sensitivity')
+    ens = golden('ensemble')
 
     def pop(tag):
         g = golden('pop_' + tag if tag != 'td3' else 'td3')
-        spread = np.abs(sens[tag + '_alt'] - g['fitness']) / np.abs(g['fitness'])
-        return np.maximum(RTOL, 50.0 * spread), spread < 1e-6
+        base = np.asarray(g['fitness'], dtype=np.float64)
+        rtol = np.full(len(base), RTOL)
+        stable = np.ones(len(base), bool)
+        for key in ens.files:
+            t, i = key.rsplit('_', 1)
+            if t == tag:
+                v = ens[key]
+                assert abs(v[0] - base[int(i)]) <= 1e-9 * abs(base[int(i)])          # same un-perturbed reference run
+                rtol[int(i)] = max(RTOL, (abs(v.mean() - v[0]) + 4.0 * v.std()) / abs(v[0]))
+                stable[int(i)] = False
+        return rtol, stable
 
     def fault(mode, actor, ref_fit):
-        spread = abs(float(sens['fault_%s_%d' % (mode, actor)]) - ref_fit) / abs(ref_fit)
-        return max(RTOL, 50.0 * spread)
+        return RTOL           # every fault / trim episode of the golden set is rounding-stable (SERL50 actors 18, 0, 7)
     return type('Tol', (), {'pop': staticmethod(pop), 'fault': staticmethod(fault), 'RTOL': RTOL})
 
 

@@ -221,6 +221,26 @@ def test_sensor_noise_wrappers_vs_reference_python(golden, mode):
     assert m['fitness'][0] == clean['fitness'][0] and m['fitness'][1] == o['fitness'][1] and m['fitness'][2] == clean['fitness'][2]
 
 
+def det_expm1f_neg(xf):
+    """expm1 of a non-positive f32 as include/serl_amd.h specifies it (the ELU branch): f64 with + - * / only, one rounding"""
+    import math
+    x = float(xf)
+    if x != x:
+        return np.float32(xf)
+    if x < -104.0:
+        return np.float32(-1.0)
+    v = x * 1.4426950408889634
+    k = -int(0.5 - v) if v < 0.0 else int(v + 0.5)
+    r = (x - k * 0.6931471803691238) - k * 1.9082149292705877e-10
+    r2 = r * r; r4 = r2 * r2; r8 = r4 * r4
+    b = [0.5 + 0.16666666666666666 * r, 0.041666666666666664 + 0.008333333333333333 * r,
+         0.001388888888888889 + 0.0001984126984126984 * r, 2.48015873015873e-05 + 2.7557319223985893e-06 * r,
+         2.755731922398589e-07 + 2.505210838544172e-08 * r, 2.08767569878681e-09 + 1.6059043836821613e-10 * r]
+    c = [b[0] + b[1] * r2, b[2] + b[3] * r2, b[4] + b[5] * r2]
+    q = r + r2 * ((c[0] + c[1] * r4) + c[2] * r8)
+    return np.float32(q if k == 0 else math.ldexp(1.0, k) * (q + 1.0) - 1.0)
+
+
 def _np_actor(w, net, obs):
     """The actor's f32 arithmetic as include/serl_amd.h specifies it, restated with numpy scalars: dot products as four
     interleaved fma partial sums, LayerNorm sums as pairwise trees per 16 rows, tanh through the f64 det_tanhf."""
@@ -269,9 +289,9 @@ def _np_actor(w, net, obs):
             q = r + r2 * ((c[0] + c[1] * r4) + c[2] * r8)
             t = q / (q + 2.0) if k == 0 else 1.0 - 2.0 / (math.ldexp(1.0, k) * (q + 1.0) + 1.0)
         return f32(-t if x < 0 else t)
-    # hidden activation: tanh, or 'relu' = LeakyReLU(0.01) (base/core/mod_utils.py:14-18); the output layer is always tanh
-    act = det_tanhf if net['activation'] == 'tanh' else (lambda v: v if v > 0 else f32(f32(0.01) * v))
-    assert net['activation'] in ('tanh', 'relu')
+    # hidden activation: tanh, 'relu' = LeakyReLU(0.01), or ELU (base/core/mod_utils.py:14-18); the output layer is always tanh
+    act = {'tanh': det_tanhf, 'relu': (lambda v: v if v > 0 else f32(f32(0.01) * v)),
+           'elu': (lambda v: v if v > 0 else det_expm1f_neg(v))}[net['activation']]
     o = 0
     W0 = w[o:o + H * S].reshape(H, S); o += H * S
     b0 = w[o:o + H]; o += H
@@ -384,3 +404,42 @@ def test_generated_references_equal_their_table():
     np.testing.assert_allclose(a['fitness'], c['fitness'], rtol=1e-10)
     x = np.linspace(0, 1, 200001)
     assert np.abs(rs.det_cospi(x) - np.cos(np.pi * x)).max() < 4e-16
+
+
+ELU_NET = dict(state_dim=7, action_dim=3, hidden=32, num_layers=3, activation='elu')
+
+
+def test_elu_activation_spec_and_closed_loop_vs_reference(golden):
+    """ELU actors (mod_utils.py:14-18: nn.ELU), which no shipped checkpoint uses: (1) det_expm1f_neg -- the libm-free
+    arithmetic the C ABI specifies for the ELU branch -- is the correctly rounded f32 expm1 on 1e5 samples and equals
+    torch.nn.ELU there; (2) the oracle's first action equals the numpy restatement of the specified arithmetic bit for bit;
+    (3) shipped SERL50 weights flown as ELU actors by the REFERENCE'S OWN Actor / Agent.evaluate
+    (tests/golden/make_elu_golden.py; two of the three crash within 2 s: early termination and penalty included):
+    forward samples to 5e-6, episode length exact, return to 1e-5."""
+    import torch
+    from oracle import rollout as R
+    from serl_amd import builds, refsignals
+    rs = np.random.RandomState(0)
+    x = np.concatenate([-np.abs(rs.randn(50000) * 3), -rs.rand(30000) * 1e-3, -rs.rand(20000) * 110]).astype(np.float32)
+    got = np.array([det_expm1f_neg(v) for v in x], dtype=np.float32)
+    exact = np.expm1(x.astype(np.float64))
+    np.testing.assert_array_equal(got, exact.astype(np.float32))          # round-to-nearest of the exact value
+    np.testing.assert_allclose(got, torch.nn.ELU()(torch.from_numpy(x)).numpy(), rtol=3e-7, atol=1e-38)
+    g = golden('elu')
+    w = golden('actors')['serl50'][g['actors']]
+    ref = refsignals.tabulate(*refsignals.base_reference(20), 20)
+    o = R.rollout(w, ELU_NET, [0, 1, 2], ref, t_max=20, traces=True)
+    x0 = builds.load('h2000_v90')[0]['x0']
+    bound = 10.0 * (3.14159265358979323846 / 180.0)
+    obs0 = np.array([0, 0, 0, x0[0], x0[1], x0[2], x0[4]], dtype=np.float64).astype(np.float32)
+    for e in range(3):
+        a = _np_actor(w[e], ELU_NET, obs0)
+        u = [-bound + float(np.float32(0.5) * (a[i] + np.float32(1.0))) * (bound - (-bound)) for i in range(3)]
+        np.testing.assert_array_equal(o['actions'][e][0], np.array(u))
+        for j in range(0, 64, 7):
+            np.testing.assert_allclose(_np_actor(w[e], ELU_NET, g['obs_samples'][j].astype(np.float32)), g['act_samples'][e][j], atol=5e-6)
+        fit, length, sm, n = g['ret'][e]
+        assert int(o['length_steps'][e]) == int(n) and o['length_t'][e] == length
+        np.testing.assert_allclose(o['fitness'][e], fit, rtol=RTOL)
+        np.testing.assert_allclose(o['actions'][e][:int(n)], g['actions_%d' % g['actors'][e]], atol=5e-3)     # (a saturating, oscillating controller: f32 rounding of the actor shows at 3e-3 rad late in the episode; the return agrees to 1e-5)
+    assert (g['ret'][:, 3] < 2001).sum() == 2
