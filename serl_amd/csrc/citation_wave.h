@@ -20,6 +20,16 @@
 #include <stdint.h>
 
 #define CITW_MAX_ROUNDS 3
+// Lanes that work for ONE episode.  64: the wavefront is the episode (rollout_wave.inc, rollout_team.inc).  32: two
+// episodes per wavefront, lanes 0-31 / 32-63 (rollout_half.inc) -- the scalar "glue" of the model costs an instruction
+// whether its 64 lanes hold one value or two, so packing two episodes into a wavefront nearly doubles the throughput in
+// the regime where wavefronts, not CUs, are the scarce resource (257 .. 2 048 episodes per GPU).  `wv` (the LDS row of
+// an episode) and every value derived from the state are then per-lane quantities; the lane-parallel phases run in
+// ceil(count / 32) passes.
+#ifndef CITW_GROUP_LANES
+#define CITW_GROUP_LANES 64
+#endif
+#define CITW_LANE ((int)(threadIdx.x & (CITW_GROUP_LANES - 1)))
 #ifndef CITW_SEARCH_BATCH
 #define CITW_SEARCH_BATCH 0     // 1 (team kernels): index-search compares in batches of eight; costs 44 VGPRs, which the one-wave kernels lack
 #endif
@@ -39,13 +49,19 @@ __shared__ int g_sidx[CITW_MAX_WAVES][64];        // interval indices of the cur
 __shared__ double g_m[CITW_MAX_WAVES][64];        // results of the lane-parallel libm calls: [2j] / [2j+1] of call j
 __shared__ double g_out0[CITW_MAX_WAVES][128];    // look-up results of round 1: [0..63] 2-D pass, [64..127] 1-D pass
 __shared__ double g_out1[CITW_MAX_WAVES][128];    // ... round 2
-__shared__ double g_out2[CITW_MAX_WAVES][128];    // ... round 3
+#ifndef CITW_OUT2_ROWS
+#define CITW_OUT2_ROWS CITW_MAX_WAVES
+#endif
+#ifndef CITW_INV_SLOTS
+#define CITW_INV_SLOTS 128
+#endif
+__shared__ double g_out2[CITW_OUT2_ROWS][128];    // ... round 3 / the per-step invariant round (no current variant has one)
 __shared__ double g_dw[CITW_MAX_WAVES][32];       // Derivative-block banks (rtDW): TimeStampA, LastUAtTimeA[12], TimeStampB, LastUAtTimeB[12]
 __shared__ double g_f[CITW_MAX_WAVES][6][20];     // ODE5 stage derivatives
 __shared__ double g_xs[CITW_MAX_WAVES][20];       // continuous states X[19] of the current stage (lane i writes state i)
 __shared__ double g_cmd[CITW_MAX_WAVES][12];      // command vector of the current env step
 __shared__ double g_act[CITW_MAX_WAVES][16][3];   // action trace of the last <= 16 env steps (flushed as one coalesced store)
-__shared__ double g_inv[CITW_MAX_WAVES][128];     // per-step invariants of the model (citw_<v>_step_invariants)
+__shared__ double g_inv[CITW_MAX_WAVES][CITW_INV_SLOTS];     // per-step invariants of the model (citw_<v>_step_invariants)
 __shared__ double g_x[256];                       // team kernels: values that cross between the wavefronts at barrier B1
 
 #define CITW_MAX_CONSTS 192
@@ -106,7 +122,17 @@ static __device__ __forceinline__ double citw_u2d(unsigned long long u) { return
 // The vectors are strictly increasing, so  lt = #{x_i < u}  is a position and  le = #{x_i <= u} = lt + (x[lt] == u);
 // rows of g_bp are padded with +inf, which no comparison below counts for finite u (and the clamp absorbs u = +inf).
 template <int MAXN>
+static __device__ __forceinline__ void citw_search_pass(const int wv, const CitwSearch *S, int lane);
+// COUNT searches of one round, one per lane of the episode's lane group, in ceil(COUNT / CITW_GROUP_LANES) passes
+template <int MAXN, int COUNT = 64>
 static __device__ __forceinline__ void citw_search(const int wv, const CitwSearch *S, int lane)
+{
+#pragma unroll
+  for (int base = 0; base < COUNT; base += CITW_GROUP_LANES) citw_search_pass<MAXN>(wv, S, lane + base);
+}
+
+template <int MAXN>
+static __device__ __forceinline__ void citw_search_pass(const int wv, const CitwSearch *S, int lane)
 {
   typedef double v2d __attribute__((ext_vector_type(2)));
   const CitwSearch d = S[lane];
@@ -151,7 +177,16 @@ static __device__ __forceinline__ void citw_search(const int wv, const CitwSearc
 }
 
 template <typename OUT>
+static __device__ __forceinline__ void citw_lookup2d_pass(const int wv, const CitwLookup *L, OUT &out, int lane);
+template <int COUNT = 64, typename OUT>
 static __device__ __forceinline__ void citw_lookup2d(const int wv, const CitwLookup *L, OUT &out, int lane)
+{
+#pragma unroll
+  for (int base = 0; base < COUNT; base += CITW_GROUP_LANES) citw_lookup2d_pass(wv, L, out, lane + base);
+}
+
+template <typename OUT>
+static __device__ __forceinline__ void citw_lookup2d_pass(const int wv, const CitwLookup *L, OUT &out, int lane)
 {
   const CitwLookup d = L[lane];
   const int ix = g_sidx[wv][d.sx], iy = g_sidx[wv][d.sy];
@@ -171,7 +206,16 @@ static __device__ __forceinline__ void citw_lookup2d(const int wv, const CitwLoo
 }
 
 template <typename OUT>
+static __device__ __forceinline__ void citw_lookup1d_pass(const int wv, const CitwLookup *L, OUT &out, int lane);
+template <int COUNT = 64, typename OUT>
 static __device__ __forceinline__ void citw_lookup1d(const int wv, const CitwLookup *L, OUT &out, int lane)
+{
+#pragma unroll
+  for (int base = 0; base < COUNT; base += CITW_GROUP_LANES) citw_lookup1d_pass(wv, L, out, lane + base);
+}
+
+template <typename OUT>
+static __device__ __forceinline__ void citw_lookup1d_pass(const int wv, const CitwLookup *L, OUT &out, int lane)
 {
   const CitwLookup d = L[lane];
   const int i = g_sidx[wv][d.sx];

@@ -29,6 +29,31 @@ SERL_DECL_WAVE(nominal) SERL_DECL_WAVE(ice) SERL_DECL_WAVE(cg_timed) SERL_DECL_W
   void serl_launch_dyn_team_##v(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
 SERL_DECL_TEAM(nominal) SERL_DECL_TEAM(ice) SERL_DECL_TEAM(cg_timed) SERL_DECL_TEAM(gust) SERL_DECL_TEAM(test)
 
+// two episodes per wavefront (rollout_half.inc): beyond one wavefront per SIMD
+#define SERL_DECL_HALF(v) void serl_launch_rollout_half_##v(const RolloutArgs &a, int grid, hipStream_t stream);
+SERL_DECL_HALF(nominal) SERL_DECL_HALF(ice) SERL_DECL_HALF(cg_timed) SERL_DECL_HALF(gust) SERL_DECL_HALF(test)
+
+static void serl_launch_rollout_half(int code, const RolloutArgs &a, int grid, hipStream_t stream)
+{
+  switch (code) {
+    case SERL_DYN_NOMINAL: serl_launch_rollout_half_nominal(a, grid, stream); break;
+    case SERL_DYN_ICE: serl_launch_rollout_half_ice(a, grid, stream); break;
+    case SERL_DYN_CG_TIMED: serl_launch_rollout_half_cg_timed(a, grid, stream); break;
+    case SERL_DYN_GUST: serl_launch_rollout_half_gust(a, grid, stream); break;
+    default: serl_launch_rollout_half_test(a, grid, stream); break;
+  }
+}
+
+// The one-wavefront-per-episode kernel runs up to 4 x CUs episodes at once (one per SIMD); beyond that the launch needs a
+// second round of wavefronts, and packing two episodes into a wavefront (1.1 x the time per env step) is the better deal.
+// H = 32 only (the lane group of an episode holds one hidden row per lane).  SERL_HALF=0 / 1 overrides.
+static bool serl_use_half(const serl_ctx *c, const serl_rollout_desc *d, int episodes)
+{
+  if (d->hidden != 32) return false;
+  if (c->env_half >= 0) return c->env_half != 0;
+  return episodes > 4 * c->num_cus;
+}
+
 // One episode per workgroup and one workgroup per CU (the LDS copy of the tables): a team finishes an env step in
 // ~0.55 of the time a lone wavefront needs (32.7 vs 59 us, four wavefronts), but only one team fits a CU where four lone wavefronts
 // would: teams while every episode gets a CU of its own (measured: 320 episodes as teams 88 us, 400 alone 59 us),
@@ -231,6 +256,20 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     a.block = 128;
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
     serl_launch_rollout_team(s.code, a, d->n_episodes, stream);
+    HIP_TRY(hipGetLastError());
+    if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
+    c->timed = timed;
+    return SERL_OK;
+  }
+  if (lanes <= 0 && serl_has_wave_kernel(s.code) && serl_use_half(c, d, together)) {
+    const int waves = (d->n_episodes + 1) / 2;
+    int wpb = (waves + c->num_cus - 1) / c->num_cus;
+    wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
+    a.lanes = 1;
+    a.block = 64 * wpb;
+    const int grid = (waves + wpb - 1) / wpb;
+    if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
+    serl_launch_rollout_half(s.code, a, grid, stream);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = timed;

@@ -295,7 +295,7 @@ class Gen:
         P('static __device__ __forceinline__ void citw_%s_step_invariants(const int wv, const int sv)' % V)
         P('{')
         P('  const CitwSearch (*S)[64] = g_S; const CitwLookup (*L)[2][64] = g_L;')
-        P('  const int lane = threadIdx.x & 63;')
+        P('  const int lane = CITW_LANE;')
         P('  (void)S; (void)L; (void)lane;')
         emitted = set()
         RI = len(self.rounds)
@@ -333,11 +333,11 @@ class Gen:
             for k, n in enumerate(R['ins']):
                 P('    g_in[wv][%d] = %s;' % (k, self.ref(n)))
             P('  }')
-            P('  citw_search<%d>(wv, S[%d], lane);' % (R['maxn'], RI))
+            P('  citw_search<%d, %d>(wv, S[%d], lane);' % (R['maxn'], len(R['searches']), RI))
             if R['L2']:
-                P('  citw_lookup2d(wv, L[%d][0], g_out%d, lane);' % (RI, RI))
+                P('  citw_lookup2d<%d>(wv, L[%d][0], g_out%d, lane);' % (len(R['L2']), RI, RI))
             if R['L1']:
-                P('  citw_lookup1d(wv, L[%d][1], g_out%d, lane);' % (RI, RI))
+                P('  citw_lookup1d<%d>(wv, L[%d][1], g_out%d, lane);' % (len(R['L1']), RI, RI))
             for e in R['L2'] + R['L1']:
                 emitted.add(e['node'])
                 P(self.stmt(e['node']))
@@ -395,7 +395,7 @@ class Gen:
         P('  const CitwSearch (*S)[64] = g_S; const CitwLookup (*L)[2][64] = g_L;')
         P('  const bool major = stage == 0;')
         P('  double STOP = 0.0;')
-        P('  const int lane = threadIdx.x & 63;')
+        P('  const int lane = CITW_LANE;')
         P('  CITW_T0();')
         emitted = set()
         done_rounds = set()
@@ -474,13 +474,13 @@ class Gen:
             for k, n in enumerate(R['ins']):
                 P('    g_in[wv][%d] = %s;' % (k, self.ref(n)))
             P('  }')
-            P('  citw_search<%d>(wv, S[%d], lane);' % (R['maxn'], r))
+            P('  citw_search<%d, %d>(wv, S[%d], lane);' % (R['maxn'], len(R['searches']), r))
             P('  CITW_T(%d);' % (4 * r + 1))
             if R['L2']:
-                P('  citw_lookup2d(wv, L[%d][0], g_out%d, lane);' % (r, r))
+                P('  citw_lookup2d<%d>(wv, L[%d][0], g_out%d, lane);' % (len(R['L2']), r, r))
             P('  CITW_T(%d);' % (4 * r + 2))
             if R['L1']:
-                P('  citw_lookup1d(wv, L[%d][1], g_out%d, lane);' % (r, r))
+                P('  citw_lookup1d<%d>(wv, L[%d][1], g_out%d, lane);' % (len(R['L1']), r, r))
             P('  CITW_T(%d);' % (4 * r + 3))
             done_rounds.add(r)
             if not self.lazy_loads:
