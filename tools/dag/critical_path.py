@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Issue floor and dependency floor of ONE model evaluation, from the DAG the kernels are generated from.
+
+  python tools/dag/critical_path.py [variant] [--latency gpurun_out/<tag>/valu_latency.json]     -> one JSON line
+
+Two lower bounds on the time of an evaluation on a team of four wavefronts, one per SIMD (what bench.py prints next to
+the measured 23 us per env step; six evaluations + one ODE5 combination make an env step):
+
+  issue floor       every live node costs at least one VALU instruction, a wave64 VALU instruction occupies its SIMD for
+                    4 cycles whatever its lanes hold, and four SIMDs share the work:
+                        sum over nodes of instr(op) x 4 cycles / 4 SIMDs
+                    with instr(op) = 1 for + - x, compares, logic; 2 for an f64 select (two v_cndmask); the measured
+                    instruction count of the compiler's IEEE division / sqrt expansion; look-ups and libm calls as the
+                    phases measured in profiles/ (they are lane-parallel: one pass serves all tables of a round).
+  dependency floor  the longest chain of dependent operations, each at its measured dependent-issue latency
+                    (tools/valu_latency.hip): no partition of the DAG over wavefronts can finish sooner.
+"""
+import os, sys, json, collections
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import build_dag
+
+LEAF = ('cf', 'ci', 'in', 'in_i', 'true', 'false', 'undef')
+# instructions per node (VALU issue slots)
+INSTR = dict(add=1, sub=1, mul=1, neg=1, fabs=1, sel=2, gt=1, ge=1, lt=1, le=1, eq=1, ne=1, band=1, bor=1, bnot=1, unord=1,
+             div=13, sqrt=15)
+# lane-parallel phases of the wave-cooperative kernels, cycles per evaluation on the wave that runs them (profiles/r01_i,
+# r01_k: search 0.9 k, 2-D 0.75 k, 1-D 0.55 k for round 1; libm group ~0.9 k)
+PHASE = dict(lookup_round1=2200, lookup_round2=900, libm=900)
+LIBM = ('sc_sin', 'sc_cos', 'sin', 'cos', 'tan', 'exp', 'log10', 'log', 'atan', 'pow', 'powsnf')
+
+
+def main():
+    variant = next((a for a in sys.argv[1:] if not a.startswith('--')), 'nominal')
+    lat = dict(dep_add_f64=8.0, dep_mul_f64=8.0, dep_div_f64=110.0, dep_sqrt_plus_add=120.0, cmp_select_add=20.0)
+    if '--latency' in sys.argv:
+        m = json.load(open(sys.argv[sys.argv.index('--latency') + 1]))
+        lat.update({k: (v[1] if isinstance(v, list) else v) for k, v in m.items() if k != 'what'})
+    g, res, _ = build_dag.build(variant, fast_zero=True)
+    roots = list(res[1]['outs'].values())
+    seen, stack = set(), list(roots)
+    while stack:
+        n = stack.pop()
+        if n in seen:
+            continue
+        seen.add(n)
+        stack.extend(build_dag.children(g, n))
+    census = collections.Counter(g.nodes[n][0] for n in seen if g.nodes[n][0] not in LEAF)
+    glue_instr = sum(INSTR.get(op, 1) * c for op, c in census.items() if op not in LIBM + ('l2d', 'l1d', 'table3'))
+    issue_cycles = glue_instr * 4 + sum(PHASE.values())
+    # dependent-latency weights (cycles)
+    L_add, L_mul = lat['dep_add_f64'], lat['dep_mul_f64']
+    W = dict(add=L_add, sub=L_add, mul=L_mul, neg=4, fabs=4, div=lat['dep_div_f64'], sqrt=lat['dep_sqrt_plus_add'] - L_add,
+             sel=lat['cmp_select_add'] - L_add, l2d=PHASE['lookup_round1'], l1d=PHASE['lookup_round1'], table3=400)
+    for f in LIBM:
+        W[f] = PHASE['libm']
+    depth, via = {}, {}
+
+    def dep(n):
+        st = [n]
+        while st:
+            m = st[-1]
+            if m in depth:
+                st.pop(); continue
+            ch = build_dag.children(g, m)
+            miss = [c for c in ch if c not in depth]
+            if miss:
+                st.extend(miss); continue
+            op = g.nodes[m][0]
+            best = max(ch, key=lambda c: depth[c], default=None)
+            depth[m] = (0 if op in LEAF else W.get(op, 4)) + (depth[best] if best is not None else 0)
+            via[m] = best
+            st.pop()
+        return depth[n]
+    end = max(roots, key=dep)
+    chain = collections.Counter()
+    n = end
+    while n is not None:
+        if g.nodes[n][0] not in LEAF:
+            chain[g.nodes[n][0]] += 1
+        n = via.get(n)
+    out = dict(variant=variant, live_nodes=sum(census.values()), census=dict(census.most_common()),
+               glue_instructions_min=glue_instr, issue_floor_cycles_per_eval_4_simds=issue_cycles / 4.0,
+               dependency_floor_cycles_per_eval=depth[end], critical_chain=dict(chain.most_common()),
+               latencies_used={k: lat[k] for k in ('dep_add_f64', 'dep_mul_f64', 'dep_div_f64', 'dep_sqrt_plus_add', 'cmp_select_add')},
+               clock_ghz=2.4)
+    per_step = lambda c: (6 * c) / 2.4e3
+    out['issue_floor_us_per_env_step'] = per_step(out['issue_floor_cycles_per_eval_4_simds'])
+    out['dependency_floor_us_per_env_step'] = per_step(out['dependency_floor_cycles_per_eval'])
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
