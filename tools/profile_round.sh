@@ -34,5 +34,5 @@ python tools/pmc_summary.py $O/pmc_sq > $O/pmc_sq.json 2>> $O/err.txt
 SERL_PROFILE=1 timeout 300 python tools/ab.py 150 192 > $O/ab.txt 2>> $O/err.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -ffp-contract=off tools/valu_latency.hip -o /tmp/valu_latency 2>> $O/err.txt && timeout 120 /tmp/valu_latency > $O/valu_latency.json 2>> $O/err.txt
 python tools/dag/critical_path.py nominal --latency $O/valu_latency.json > $O/critical_path.json 2>> $O/err.txt
-rm -rf $O/prof $O/prof_serl10 $O/prof_pop512     # (the databases are large; their summaries stay)
+rm -rf $O/prof $O/prof_serl10 $O/prof_pop512 $O/pmc_fetch $O/pmc_write $O/pmc_sq     # (the databases are large; their summaries stay)
 ls -la $O
