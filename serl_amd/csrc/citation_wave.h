@@ -39,40 +39,109 @@ struct CitwSearch { uint16_t row, n, in, pad; };                                
 struct CitwBpVec { uint16_t xw, n; };                                           // a distinct breakpoint vector: word offset in g_ro, entries
 struct CitwLookup { uint16_t xrw, nr, xcw, zw, sx, sy, in0, in1, out, p0, p1, p2; };   // 24 B; 1-D: x = xrw, y = zw
 
-// Per-wavefront LDS scratch, one row per wavefront of the workgroup.  Separate objects (not one struct) so that the
-// compiler can tell the blackboards apart: results of look-up round 1 stay loadable across the stores of round 2.
+// Per-wavefront LDS scratch, one row per wavefront of the workgroup.
 #ifndef CITW_MAX_WAVES
 #define CITW_MAX_WAVES 4          // wavefronts (episodes) per workgroup; 8 = two per SIMD with 256 registers each
 #endif
-__shared__ double g_in[CITW_MAX_WAVES][32];       // look-up inputs of the current round
-__shared__ int g_sidx[CITW_MAX_WAVES][64];        // interval indices of the current round
-__shared__ double g_m[CITW_MAX_WAVES][64];        // results of the lane-parallel libm calls: [2j] / [2j+1] of call j
-__shared__ double g_out0[CITW_MAX_WAVES][128];    // look-up results of round 1: [0..63] 2-D pass, [64..127] 1-D pass
-__shared__ double g_out1[CITW_MAX_WAVES][128];    // ... round 2
+#ifndef CITW_M_ROWS
+#define CITW_M_ROWS CITW_MAX_WAVES
+#endif
 #ifndef CITW_OUT2_ROWS
 #define CITW_OUT2_ROWS CITW_MAX_WAVES
 #endif
 #ifndef CITW_INV_SLOTS
 #define CITW_INV_SLOTS 128
 #endif
-__shared__ double g_out2[CITW_OUT2_ROWS][128];    // ... round 3 / the per-step invariant round (no current variant has one)
-__shared__ double g_dw[CITW_MAX_WAVES][32];       // Derivative-block banks (rtDW): TimeStampA, LastUAtTimeA[12], TimeStampB, LastUAtTimeB[12]
-__shared__ double g_f[CITW_MAX_WAVES][6][20];     // ODE5 stage derivatives
-__shared__ double g_xs[CITW_MAX_WAVES][20];       // continuous states X[19] of the current stage (lane i writes state i)
-__shared__ double g_cmd[CITW_MAX_WAVES][12];      // command vector of the current env step
-__shared__ double g_act[CITW_MAX_WAVES][16][3];   // action trace of the last <= 16 env steps (flushed as one coalesced store)
-__shared__ double g_inv[CITW_MAX_WAVES][CITW_INV_SLOTS];     // per-step invariants of the model (citw_<v>_step_invariants)
-__shared__ double g_x[256];                       // team kernels: values that cross between the wavefronts at barrier B1
-
+#ifndef CITW_LDS_EXTRA_FLOATS
+#define CITW_LDS_EXTRA_FLOATS 4         // team kernels: the actor hand-over words and the LDS-resident actor weights
+#endif
 #define CITW_MAX_CONSTS 192
-__shared__ double g_k[CITW_MAX_CONSTS];           // f64 literals of the model (only when generated with --lds-consts)
-__shared__ double g_ro[CITW_RO_LDS_WORDS];
-__shared__ double g_t3[48];
 #define CITW_MAX_BPVEC 48
 #define CITW_BP_PAD 24
+
+#ifdef CITW_LDS_STRUCT
+// ONE LDS object with an explicit member order.  A DS instruction reaches the first 64 KB of LDS with its 16-bit immediate
+// offset; anything above needs its address in a VGPR (a v_mov per base in the ISA).  Left to itself the compiler put the
+// 96 KB table block first and the per-episode blackboards -- the hot, constant-address accesses of the generated code --
+// behind it (377 of 466 DS instructions of the team kernel without an immediate offset).  Hence: blackboards, exchange
+// rows, flags and descriptors first (~45 KB), the table block last.
+struct CitwLds {
+  double xs[CITW_MAX_WAVES][20];          // continuous states X[19] of the current stage (lane i writes state i)
+  double cmd[CITW_MAX_WAVES][12];         // command vector of the current env step
+  double in[CITW_MAX_WAVES][32];          // look-up inputs of the current round
+  int sidx[CITW_MAX_WAVES][64];           // interval indices of the current round
+  double m[CITW_M_ROWS][64];              // results of the lane-parallel libm calls: [2j] / [2j+1] of call j (team kernels: one row per wavefront)
+  double out0[CITW_MAX_WAVES][128];       // look-up results of round 1: [0..63] 2-D pass, [64..127] 1-D pass
+  double out1[CITW_MAX_WAVES][128];       // ... round 2
+  double out2[CITW_OUT2_ROWS][128];       // ... round 3 / the per-step invariant round (no current variant has one)
+  double dw[CITW_MAX_WAVES][32];          // Derivative-block banks (rtDW): TimeStampA, LastUAtTimeA[12], TimeStampB, LastUAtTimeB[12]
+  double f[CITW_MAX_WAVES][6][20];        // ODE5 stage derivatives
+  double act[CITW_MAX_WAVES][16][3];      // action trace of the last <= 16 env steps (flushed as one coalesced store)
+  double inv[CITW_MAX_WAVES][CITW_INV_SLOTS];   // per-step invariants of the model (citw_<v>_step_invariants)
+  double x[256];                          // team kernels: values that cross between the wavefronts at barrier B1
+  double t3[48];
+  unsigned flag[8], iflag[8];             // hand-over flags of the team kernels (citw_flag_*, citw_iflag_*)
+  alignas(16) float extra[CITW_LDS_EXTRA_FLOATS];     // unit-specific words (team kernels: actor hand-over + LDS-resident actor weights)
+  double k[CITW_MAX_CONSTS];              // f64 literals of the model (only when generated with --lds-consts)
+  CitwSearch S[CITW_MAX_ROUNDS][64];
+  CitwLookup L[CITW_MAX_ROUNDS][2][64];
+  double bp[CITW_MAX_BPVEC][CITW_BP_PAD]; // the distinct breakpoint vectors, padded with +inf (index search without bounds tests)
+  double ro[CITW_RO_LDS_WORDS];           // the model's tables (.rodata words the evaluation reads): 94 KB, last
+};
+__shared__ CitwLds citw_lds;
+#define g_xs citw_lds.xs
+#define g_cmd citw_lds.cmd
+#define g_in citw_lds.in
+#define g_sidx citw_lds.sidx
+#define g_m citw_lds.m
+#define g_out0 citw_lds.out0
+#define g_out1 citw_lds.out1
+#define g_out2 citw_lds.out2
+#define g_dw citw_lds.dw
+#define g_f citw_lds.f
+#define g_act citw_lds.act
+#define g_inv citw_lds.inv
+#define g_x citw_lds.x
+#define g_t3 citw_lds.t3
+#define g_flag citw_lds.flag
+#define g_iflag citw_lds.iflag
+#define g_k citw_lds.k
+#define g_S citw_lds.S
+#define g_L citw_lds.L
+#define g_bp citw_lds.bp
+#define g_ro citw_lds.ro
+
+#else
+// Separate objects: distinct objects let the compiler tell the blackboards apart (results of look-up round 1 stay loadable
+// across the stores of round 2, a store to g_f[..][stage] does not order the loads around it).  The compiler lays the LDS
+// objects of a kernel out by DESCENDING ALIGNMENT (then size): the blackboards are over-aligned to 64 bytes so that they come
+// first and the 94 KB table block (and the breakpoint / descriptor tables, 8-byte aligned) last -- a DS instruction reaches
+// the first 64 KB with its 16-bit immediate offset, anything above needs its address in a VGPR (left to the default order
+// 377 of the team kernel's 466 DS instructions had none).
+__shared__ alignas(64) double g_in[CITW_MAX_WAVES][32];       // look-up inputs of the current round
+__shared__ alignas(64) int g_sidx[CITW_MAX_WAVES][64];        // interval indices of the current round
+__shared__ alignas(64) double g_m[CITW_M_ROWS][64];           // results of the lane-parallel libm calls: [2j] / [2j+1] of call j (team kernels: one row per wavefront)
+__shared__ alignas(64) double g_out0[CITW_MAX_WAVES][128];    // look-up results of round 1: [0..63] 2-D pass, [64..127] 1-D pass
+__shared__ alignas(64) double g_out1[CITW_MAX_WAVES][128];    // ... round 2
+__shared__ alignas(64) double g_out2[CITW_OUT2_ROWS][128];    // ... round 3 / the per-step invariant round (no current variant has one)
+__shared__ alignas(64) double g_dw[CITW_MAX_WAVES][32];       // Derivative-block banks (rtDW): TimeStampA, LastUAtTimeA[12], TimeStampB, LastUAtTimeB[12]
+__shared__ alignas(64) double g_f[CITW_MAX_WAVES][6][20];     // ODE5 stage derivatives
+__shared__ alignas(64) double g_xs[CITW_MAX_WAVES][20];       // continuous states X[19] of the current stage (lane i writes state i)
+__shared__ alignas(64) double g_cmd[CITW_MAX_WAVES][12];      // command vector of the current env step
+__shared__ alignas(64) double g_act[CITW_MAX_WAVES][16][3];   // action trace of the last <= 16 env steps (flushed as one coalesced store)
+__shared__ alignas(64) double g_inv[CITW_MAX_WAVES][CITW_INV_SLOTS];     // per-step invariants of the model (citw_<v>_step_invariants)
+__shared__ alignas(64) double g_x[256];                       // team kernels: values that cross between the wavefronts at barrier B1
+
+__shared__ alignas(64) double g_k[CITW_MAX_CONSTS];           // f64 literals of the model (only when generated with --lds-consts)
+__shared__ double g_ro[CITW_RO_LDS_WORDS];
+__shared__ alignas(64) double g_t3[48];
 __shared__ double g_bp[CITW_MAX_BPVEC][CITW_BP_PAD];   // the distinct breakpoint vectors, padded with +inf (index search without bounds tests)
 __shared__ CitwSearch g_S[CITW_MAX_ROUNDS][64];
 __shared__ CitwLookup g_L[CITW_MAX_ROUNDS][2][64];
+
+__shared__ alignas(64) unsigned g_flag[8];       // hand-over flags of the team kernels, one per producing wavefront (citw_flag_*)
+__shared__ alignas(64) unsigned g_iflag[8];      // ... and for look-up inputs computed by helper wavefronts (citw_iflag_*)
+#endif
 
 // Phase profile of the model evaluation (profiling builds only, -DCITW_PROFILE): shader-clock cycles of wave 0 of
 // workgroup 0 between the CITW_T marks of the generated code, accumulated in LDS and copied out by the kernel.
@@ -102,7 +171,6 @@ __shared__ unsigned long long g_tlastw[4];    // ... and for waves 2, 3 (barrier
 // Hand-over of a look-up input from a helper wavefront to wave 0 without a barrier (team kernels): the helper stores the
 // value(s), then the sequence number of the evaluation (release); wave 0 polls the number (acquire) before it reads.
 // All wavefronts of a workgroup are resident, so the poll cannot starve the writer; numbers only grow within an episode.
-__shared__ unsigned g_flag[4];       // one per producing wavefront of the team
 static __device__ __forceinline__ void citw_flag_raise(int q, unsigned seq)
 {
   if ((threadIdx.x & 63) == 0) __hip_atomic_store(&g_flag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -112,6 +180,16 @@ static __device__ __forceinline__ void citw_flag_wait(int q, unsigned seq)
   // "reached", not "equal": a producer can never be an evaluation ahead (barrier B2 separates evaluations), but a poll that
   // tolerates it cannot hang either
   while ((int)(__hip_atomic_load(&g_flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) __builtin_amdgcn_s_sleep(1);
+}
+
+// ... and a second set for the look-up inputs a helper wavefront computes for wave 0 (spread-input partitions)
+static __device__ __forceinline__ void citw_iflag_raise(int q, unsigned seq)
+{
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(&g_iflag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+static __device__ __forceinline__ void citw_iflag_wait(int q, unsigned seq)
+{
+  while ((int)(__hip_atomic_load(&g_iflag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) __builtin_amdgcn_s_sleep(1);
 }
 
 static __device__ __forceinline__ unsigned long long citw_d2u(double d) { return (unsigned long long)__double_as_longlong(d); }

@@ -153,7 +153,7 @@ static __device__ __forceinline__ float serl_act(float v, int act)
 // weight chunk, then the output layer).  The rollout kernels whose wavefront owns a whole episode pass nothing; the team
 // kernels' ACTOR WAVEFRONT uses it to pay its share of the workgroup barriers while it works (SerlBarrierCredit).
 struct SerlNoSync { __device__ __forceinline__ void operator()(int, int) const {} };
-// The actor wavefront of a team runs beside the four wavefronts that integrate the model (rollout_team.inc); the hardware
+// The actor wavefront of a team runs beside the wavefronts that integrate the model (rollout_team.inc); the hardware
 // barrier counts every wavefront of the workgroup, so it executes the step's `per_step` barriers too -- spread evenly
 // over the pieces of its forward pass, so that it is early at every one of them and never holds the team up.
 struct SerlBarrierCredit {

@@ -23,7 +23,7 @@ void serl_launch_dyn_ice(const RolloutArgs &a, const double *cmds, double *state
   void serl_launch_dyn_wave_##v(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
 SERL_DECL_WAVE(nominal) SERL_DECL_WAVE(ice) SERL_DECL_WAVE(cg_timed) SERL_DECL_WAVE(gust) SERL_DECL_WAVE(test)
 
-// a team of wavefronts per episode (rollout_team.inc): the latency-bound regime
+// a team of wavefronts per episode (rollout_team.inc: 7 + the actor wavefront, two per SIMD): the latency-bound regime
 #define SERL_DECL_TEAM(v)                                                                                     \
   void serl_launch_rollout_team_##v(const RolloutArgs &a, int grid, hipStream_t stream);                          \
   void serl_launch_dyn_team_##v(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
@@ -55,7 +55,7 @@ static bool serl_use_half(const serl_ctx *c, const serl_rollout_desc *d, int epi
 }
 
 // One episode per workgroup and one workgroup per CU (the LDS copy of the tables): a team finishes an env step in
-// ~0.55 of the time a lone wavefront needs (32.7 vs 59 us, four wavefronts), but only one team fits a CU where four lone wavefronts
+// ~0.37 of the time a lone wavefront needs (21.2 vs 57 us), but only one team fits a CU where four lone wavefronts
 // would: teams while every episode gets a CU of its own (measured: 320 episodes as teams 88 us, 400 alone 59 us),
 // lone wavefronts beyond.  SERL_TEAM=0 / 1 overrides.
 static bool serl_use_team(const serl_ctx *c, int code, int episodes)

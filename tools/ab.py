@@ -25,7 +25,8 @@ for E in [int(x) for x in sys.argv[1:]] or [150, 1024]:
         eng.lib.serl_debug_profile(eng.ctx, buf)
         st = max(buf[3], 1)
         res['cyc_E%d' % E] = [int(buf[0] / st), int(buf[1] / st), int(buf[2] / st)]
-        if any(buf[4:]):
+        res['simd_E%d' % E] = [int(v) - 100 for v in buf[16:25] if v]      # SIMD of every wavefront of workgroup 0
+        if any(buf[4:16]):
             res['phase_E%d' % E] = [int(v / st) for v in buf[4:32]]
     res['fit0_E%d' % E] = float(out['fitness'][0])
 print(os.environ.get('SERL_LIB', 'default'), json.dumps(res))

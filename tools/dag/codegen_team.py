@@ -3,7 +3,11 @@
 
 With one wavefront per SIMD every instruction -- VALU, SALU, LDS, waitcnt -- costs a 4-cycle issue slot, so one model
 evaluation (~4 500 instructions) is issue-bound on a single wavefront.  When there are fewer episodes than CUs, the
-other SIMDs of the CU take a share of the work: a team of K wavefronts (K = 4 by default: one per SIMD of the CU) per episode.
+other SIMDs of the CU take a share of the work: a team of K wavefronts per episode.  K = 7 by default (round 2): with the
+actor wavefront of rollout_team.inc that makes eight wavefronts, TWO per SIMD -- a wavefront alone on a SIMD pays 7.6 cycles
+per dependent f64 operation and ~85 per LDS round trip with nothing to fill them; a neighbour on the same SIMD issues into
+those gaps, and a wavefront parked at a barrier leaves the whole SIMD to its neighbour, which evens out what the static
+balance below misses.  Measured (150 episodes, us per env step): K = 4: 22.8 - 23.7, 5: 22.9, 6: 21.7, 7: 21.2.
 
   wave 0 (main)     cones of the round-1 look-up inputs (all but the one behind the libm pow chain) -> [poll the flag of the
                     wave that hands that input over] -> index search, 2-D and 1-D interpolation passes -> [barrier B1]
@@ -25,9 +29,12 @@ order per value) is that of the single-wave code: results are bit-identical.
 
 Knobs (environment, for sweeps; defaults are the measured best): CITW_TEAM_WAVES, CITW_TEAM_LOOKUP_COST,
 CITW_TEAM_ROUND2_COST, CITW_TEAM_AFFINITY, CITW_TEAM_SHARE_LIBM, CITW_TEAM_SPLIT_INPUTS, CITW_TEAM_FN_SCALE,
-CITW_TEAM_LIBM_SCALE, CITW_TEAM_POST_BIAS, CITW_TEAM_IMPORT_COST, CITW_TEAM_AFFINITY_POST.
+CITW_TEAM_LIBM_SCALE, CITW_TEAM_POST_BIAS, CITW_TEAM_IMPORT_COST, CITW_TEAM_AFFINITY_POST; and two that were measured
+and stay off (profiles/r02_team_experiments.md): CITW_TEAM_SPREAD_INPUTS (every round-1 input cone on a helper, handed to
+wave 0 by flags: 24.0 - 26.0), CITW_TEAM_SIMD_PAIRS (balance per SIMD instead of per wavefront: 22.6 - 23.4).
 
-Usage: python tools/dag/codegen_team.py [variant ...]      (CITW_TEAM_WAVES=2|3|4 overrides the team size)
+Usage: python tools/dag/codegen_team.py [variant ...] [--suffix=_tag]      (CITW_TEAM_WAVES=2..7 overrides the team size;
+       --suffix writes gen/citation_<variant>_team_tag.inc for tools/exp_build.py A/B builds)
 """
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -35,20 +42,24 @@ import build_dag, codegen
 from codegen import LOOKUPS, hexf
 
 LEAF = ('cf', 'ci', 'in', 'in_i', 'true', 'false')
-TEAM_WAVES = int(os.environ.get('CITW_TEAM_WAVES', 4))
+TEAM_WAVES = int(os.environ.get('CITW_TEAM_WAVES', 7))
 # instruction estimates used by the balancer (wave 0's fixed work: search + 2-D + 1-D passes; later look-up rounds)
 LOOKUP_PHASES = int(os.environ.get('CITW_TEAM_LOOKUP_COST', 1400))
 POST_ROUND2_COST = int(os.environ.get('CITW_TEAM_ROUND2_COST', 300))
 IMPORT_COST = float(os.environ.get('CITW_TEAM_IMPORT_COST', 0.0))         # units per value a wave fetches from LDS behind B1
-# initial load per wave behind B1.  Measured (profiles/r01_i_phase_profile.md): the last wave -- the one that hands the pow chain
-# over -- needs 22.7 k cycles behind B1 for 158 nodes where the others need 12-14 k for 107-134: bias it by 100 units
-POST_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_POST_BIAS', '0,0,0,100').split(',') if v]
+# initial load per wave behind B1 (round 1, K = 4: the wave that hands the pow chain over needed a bias of 100 units; with two
+# wavefronts per SIMD the hardware evens that out and no bias measures best)
+POST_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_POST_BIAS', '0').split(',') if v]
 AFFINITY_POST = float(os.environ.get('CITW_TEAM_AFFINITY_POST', 0.0))
 SHARE_LIBM = int(os.environ.get('CITW_TEAM_SHARE_LIBM', 1))           # 1: every libm call is made by one wave, the others read the result (flag hand-over)
+SPREAD_IN = int(os.environ.get('CITW_TEAM_SPREAD_INPUTS', 0))         # 1: EVERY round-1 input cone runs on a helper; wave 0 waits for their input flags (g_iflag), then looks up
+SIMD_PAIRS = int(os.environ.get('CITW_TEAM_SIMD_PAIRS', 0))            # 1: the balancer counts the load of a SIMD (waves b and b + 4 share one) instead of a wave's
+ACTOR_UNITS = float(os.environ.get('CITW_TEAM_ACTOR_UNITS', 550))     # the actor wavefront (wave index K) as load on the SIMD it shares, units per evaluation
+ACTOR_POST = float(os.environ.get('CITW_TEAM_ACTOR_POST', 0))
 SPLIT_IN = int(os.environ.get('CITW_TEAM_SPLIT_INPUTS', 1))           # 1: the heaviest round-1 input cone (pow chain) runs on a helper, handed over by flag
 FN_SCALE = float(os.environ.get('CITW_TEAM_FN_SCALE', 1.0))            # libm bodies relative to the first estimates in FN
 LIBM_SCALE = float(os.environ.get('CITW_TEAM_LIBM_SCALE', 1.0))        # extra factor for the handed-over cone's libm bodies
-AFFINITY = float(os.environ.get('CITW_TEAM_AFFINITY', 2.0))            # > 0: a sink leans towards the wave that already holds most of its cone
+AFFINITY = float(os.environ.get('CITW_TEAM_AFFINITY', 1.0))            # > 0: a sink leans towards the wave that already holds most of its cone
 CW = dict(div=11, sqrt=15, sel=3, unord=2, table3=120)
 FN = dict(sc_sin=100, sc_cos=100, sin=100, cos=100, tan=120, exp=40, log10=60, log=60, atan=80, pow=250)
 
@@ -114,16 +125,46 @@ class TeamGen(codegen.Gen):
             if any(g.nodes[m][0] in FN for m in full_cone(heavy)):
                 self.P = K - 1
                 self.in_owner[heavy] = self.P
+        self.spread = bool(SPREAD_IN and K > 2 and ins0 and SHARE_LIBM)
+        if self.spread:
+            # every input cone goes to a helper (heaviest first, to the least loaded one; the pow chain stays with P); wave 0
+            # keeps the look-up phases only
+            hl = [0.0] * K
+            hh = [set() for _ in range(K)]
+            if self.P is not None:
+                cone = full_cone(next(n for n in ins0 if self.in_owner[n] == self.P))
+                hh[self.P] |= cone; hl[self.P] += sum(cost(m) for m in cone) + sum(FN.get(g.nodes[m][0], 0) for m in cone)
+            for n in sorted([n for n in ins0 if self.in_owner[n] == 0 and weight(n) > 0], key=lambda n: (-weight(n), ins0.index(n))):
+                cone = full_cone(n)
+                b = min(range(1, K), key=lambda q: (hl[q] + sum(cost(m) for m in cone if m not in hh[q]), q))
+                hl[b] += sum(cost(m) for m in cone if m not in hh[b]); hh[b] |= cone
+                self.in_owner[n] = b
         A0w = self.closure([n for n in ins0 if self.in_owner[n] == 0 and n in S0], S0)       # wave 0's share of A0
         have = [set(A0w)] + [set() for _ in range(K - 1)]
         load = [sum(cost(m) for m in A0w) + fn_cost(A0w, 0, True) + LOOKUP_PHASES] + [0.0] * (K - 1)
         self.handed = set()
+        self.handed_of = {b: set() for b in range(K)}
+        for n in ins0:
+            b = self.in_owner[n]
+            if b != 0:
+                self.handed_of[b] |= self.closure([n], S0)
         if self.P is not None:
-            for n in ins0:
-                if self.in_owner[n] == self.P:
-                    self.handed |= self.closure([n], S0)
-            have[self.P] |= self.handed
-            load[self.P] += sum(cost(m) for m in self.handed) + LIBM_SCALE * fn_cost(self.handed, self.P, True)
+            self.handed = set(self.handed_of[self.P])
+        for b in range(1, K):
+            if self.handed_of[b]:
+                have[b] |= self.handed_of[b]
+                load[b] += sum(cost(m) for m in self.handed_of[b]) + (LIBM_SCALE if b == self.P else 1.0) * fn_cost(self.handed_of[b], b, True)
+        def simd_extra(q, ld, actor=ACTOR_UNITS):
+            """what else runs on wave q's SIMD (wavefronts q and q +- 4 share one; the actor wavefront is wave K)"""
+            if not SIMD_PAIRS:
+                return 0.0
+            x = 0.0
+            for p in (q - 4, q + 4):
+                if 0 <= p < K:
+                    x += ld[p]
+                elif p == K:
+                    x += actor
+            return x
         # ---- who makes which libm call (shared results): the calls of the handed-over cone belong to P, the other groups
         # (one function body each) go to the helpers, heaviest first
         self.call_owner = {}
@@ -138,18 +179,20 @@ class TeamGen(codegen.Gen):
                 have[b] |= cone
                 have[b] |= set(self.libm_calls[j][1].values())
             for j in range(len(self.libm_calls)):
-                if self.P is not None and any(nd in self.handed for nd in self.libm_calls[j][1].values()):
-                    if grp(j) not in fns[self.P]:
-                        load[self.P] += LIBM_SCALE * gcost(grp(j))
-                        fns[self.P].add(grp(j))
-                    give(self.P, j)
+                own = [b for b in range(1, K) if any(nd in self.handed_of[b] for nd in self.libm_calls[j][1].values())]
+                if own:
+                    b = self.P if self.P in own else own[0]
+                    if grp(j) not in fns[b]:
+                        load[b] += (LIBM_SCALE if b == self.P else 1.0) * gcost(grp(j))
+                        fns[b].add(grp(j))
+                    give(b, j)
             groups = collections.defaultdict(list)
             for j in range(len(self.libm_calls)):
                 if j not in self.call_owner:
                     groups[grp(j)].append(j)
             helpers = list(range(1, K))
             for f, calls in sorted(groups.items(), key=lambda kv: (-gcost(kv[0]), kv[0])):
-                b = min(helpers, key=lambda q: (load[q], q))
+                b = min(helpers, key=lambda q: (load[q] + simd_extra(q, load) + (0.01 * load[q] if SIMD_PAIRS else 0.0), q))
                 load[b] += gcost(f)
                 for j in calls:
                     give(b, j)
@@ -161,7 +204,7 @@ class TeamGen(codegen.Gen):
                 add = [m for m in cones[n] if m not in have[b]]
                 res.append(load[b] + sum(cost(m) for m in add) + fn_cost(add, b))
             # AFFINITY > 0 leans towards the wave that already holds most of the cone (less recomputation overall)
-            b = min(range(K), key=lambda q: (res[q] + AFFINITY * (res[q] - load[q]), q))
+            b = min(range(K), key=lambda q: (res[q] + simd_extra(q, load) + AFFINITY * (res[q] - load[q]) + (0.01 * res[q] if SIMD_PAIRS else 0.0), q))
             add = [m for m in cones[n] if m not in have[b]]
             load[b] = res[b]
             fn_cost(add, b, True)
@@ -187,7 +230,7 @@ class TeamGen(codegen.Gen):
             return sum(cost(m) for m in new) + IMPORT_COST * len(ins), ins
         for n in sorted(psinks, key=lambda n: (-sum(cost(m) for m in pcones[n]), n)):
             res = [pload[b] + pcost(n, b)[0] for b in range(K)]
-            b = 0 if self.rnd[n] >= 2 else min(range(K), key=lambda q: (res[q] + AFFINITY_POST * (res[q] - pload[q]), q))
+            b = 0 if self.rnd[n] >= 2 else min(range(K), key=lambda q: (res[q] + simd_extra(q, pload, ACTOR_POST) + AFFINITY_POST * (res[q] - pload[q]) + (0.01 * res[q] if SIMD_PAIRS else 0.0), q))
             pins[b].update(pcost(n, b)[1])
             phave[b].update(pcones[n]); pload[b] = res[b]; powner[n] = b
         self.post, self.phave, self.powner, self.post_load = post, phave, powner, pload
@@ -411,7 +454,11 @@ class TeamGen(codegen.Gen):
                 B('  }')
                 if r == 0:
                     B('  %s;' % TM(5))
-                    if self.P is not None:
+                    if self.spread:
+                        for q in sorted(set(self.in_owner.values()) - {0}):
+                            B('  citw_iflag_wait(%d, %s);   /* the look-up inputs wave %d computes are in g_in[0] */' % (q, SEQ, q))
+                        B('  %s;' % TM(9))
+                    elif self.P is not None:
                         if self.P not in waited:
                             B('  citw_flag_wait(%d, %s);   /* the input(s) wave %d computes are in g_in[0] */' % (self.P, SEQ, self.P))
                             waited.add(self.P)
@@ -458,7 +505,9 @@ class TeamGen(codegen.Gen):
                 for n in self.inv_frontier:
                     B(self.inv_load(n))
                     emitted.add(n)
-            if b == self.P:
+            if self.spread:
+                pass          # (inputs follow the libm phase below)
+            elif b == self.P:
                 B('  /* ---- first of all: the look-up input(s) wave 0 waits for (libm pow chain of the air data) */')
                 if shared:
                     libm_phase_shared(only=set(j for j in self.calls_of.get(b, []) if any(nd in self.handed for nd in self.libm_calls[j][1].values())), raise_flag=False)
@@ -478,6 +527,18 @@ class TeamGen(codegen.Gen):
                 libm_phase_shared()
             else:
                 libm_phase(self.have[b])
+            if self.spread and b != 0 and any(o == b for o in self.in_owner.values()):
+                B('  /* ---- the round-1 look-up inputs this wave computes for wave 0 (their cones), handed over by flag */')
+                for k, n in enumerate(self.rounds[0]['ins']):
+                    if self.in_owner[n] == b:
+                        emit_node(n, self.have[b])
+                B('  if (lane == 0) {')
+                for k, n in enumerate(self.rounds[0]['ins']):
+                    if self.in_owner[n] == b:
+                        B('    g_in[0][%d] = %s;' % (k, self.ref(n)))
+                B('  }')
+                B('  citw_iflag_raise(%d, %s);' % (b, SEQ))
+                B('  __builtin_amdgcn_sched_barrier(0);     /* nothing of what follows may be scheduled in front of the hand-over */')
             B('  %s;' % TM(4))
             if b == 0:
                 lookup_round(0, self.rounds[0], None)
@@ -572,7 +633,8 @@ def main():
     for v in variants:
         gen = TeamGen(v, hoist='--hoist-invariants' in sys.argv)
         text = gen.emit_team()
-        path = os.path.join(build_dag.ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_team.inc' % v)
+        suffix = next((a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--suffix=')), '')     # experiments: --suffix=_exp7
+        path = os.path.join(build_dag.ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_team%s.inc' % (v, suffix))
         open(path, 'w').write(text)
         print('%s: %d lines; %d waves; pre-barrier glue %s (load estimate %s), post %s (%s), exchanged %d, xdot owners %s'
               % (path, text.count('\n'), gen.K, [len(h) for h in gen.have], gen.load_estimate, [len(h) for h in gen.phave],
