@@ -10,7 +10,8 @@ those gaps, and a wavefront parked at a barrier leaves the whole SIMD to its nei
 balance below misses.  Measured (150 episodes, us per env step): K = 4: 22.8 - 23.7, 5: 22.9, 6: 21.7, 7: 21.2.
 
   wave 0 (main)     cones of the round-1 look-up inputs (all but the one behind the libm pow chain) -> [poll the flag of the
-                    wave that hands that input over] -> index search, 2-D and 1-D interpolation passes -> [barrier B1]
+                    wave that hands that input over] -> index search -> [raise its flag: wave 1 runs the 1-D interpolation
+                    pass from here on] -> 2-D interpolation pass -> [barrier B1]
                     -> later look-up rounds, its share of the derivative cones -> [barrier B2]
   waves 1..K-1      the libm calls of the evaluation, each made by exactly ONE wave (lane-parallel), results in its g_m row,
   (helpers)         published by an LDS flag (release store of the evaluation's sequence number; a consumer polls it
@@ -53,6 +54,8 @@ POST_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_POST_BIAS', '0').split(
 AFFINITY_POST = float(os.environ.get('CITW_TEAM_AFFINITY_POST', 0.0))
 SHARE_LIBM = int(os.environ.get('CITW_TEAM_SHARE_LIBM', 1))           # 1: every libm call is made by one wave, the others read the result (flag hand-over)
 SPREAD_IN = int(os.environ.get('CITW_TEAM_SPREAD_INPUTS', 0))         # 1: EVERY round-1 input cone runs on a helper; wave 0 waits for their input flags (g_iflag), then looks up
+OFFLOAD_1D = int(os.environ.get('CITW_TEAM_OFFLOAD_1D', 1))          # 1: the 1-D interpolation pass of round 1 runs on helper wave 1 (after wave 0's index search, by flag) beside wave 0's 2-D pass
+SPREAD_MIN = float(os.environ.get('CITW_TEAM_SPREAD_MIN', 0))         # with SPREAD_INPUTS: only input cones at least this heavy (units) leave wave 0
 SIMD_PAIRS = int(os.environ.get('CITW_TEAM_SIMD_PAIRS', 0))            # 1: the balancer counts the load of a SIMD (waves b and b + 4 share one) instead of a wave's
 ACTOR_UNITS = float(os.environ.get('CITW_TEAM_ACTOR_UNITS', 550))     # the actor wavefront (wave index K) as load on the SIMD it shares, units per evaluation
 ACTOR_POST = float(os.environ.get('CITW_TEAM_ACTOR_POST', 0))
@@ -134,7 +137,7 @@ class TeamGen(codegen.Gen):
             if self.P is not None:
                 cone = full_cone(next(n for n in ins0 if self.in_owner[n] == self.P))
                 hh[self.P] |= cone; hl[self.P] += sum(cost(m) for m in cone) + sum(FN.get(g.nodes[m][0], 0) for m in cone)
-            for n in sorted([n for n in ins0 if self.in_owner[n] == 0 and weight(n) > 0], key=lambda n: (-weight(n), ins0.index(n))):
+            for n in sorted([n for n in ins0 if self.in_owner[n] == 0 and weight(n) > SPREAD_MIN], key=lambda n: (-weight(n), ins0.index(n))):
                 cone = full_cone(n)
                 b = min(range(1, K), key=lambda q: (hl[q] + sum(cost(m) for m in cone if m not in hh[q]), q))
                 hl[b] += sum(cost(m) for m in cone if m not in hh[b]); hh[b] |= cone
@@ -142,6 +145,10 @@ class TeamGen(codegen.Gen):
         A0w = self.closure([n for n in ins0 if self.in_owner[n] == 0 and n in S0], S0)       # wave 0's share of A0
         have = [set(A0w)] + [set() for _ in range(K - 1)]
         load = [sum(cost(m) for m in A0w) + fn_cost(A0w, 0, True) + LOOKUP_PHASES] + [0.0] * (K - 1)
+        self.h1d = 1 if (OFFLOAD_1D and K > 2 and self.rounds[0]['L1']) else None
+        if self.h1d is not None:
+            load[self.h1d] += 220.0            # the 1-D pass it takes over from wave 0
+            load[0] -= 220.0
         self.handed = set()
         self.handed_of = {b: set() for b in range(K)}
         for n in ins0:
@@ -464,13 +471,15 @@ class TeamGen(codegen.Gen):
                             waited.add(self.P)
                         B('  %s;' % TM(9))
                 B('  citw_search<%d>(wv, S[%d], lane);' % (R['maxn'], r))
+                if r == 0 and self.h1d is not None:
+                    B('  citw_iflag_raise(0, %s);   /* interval indices are in g_sidx[0]: wave %d runs the 1-D pass beside the 2-D pass */' % (SEQ, self.h1d))
                 if r == 0:
                     B('  %s;' % TM(6))
                 if R['L2']:
                     B('  citw_lookup2d(wv, L[%d][0], g_out%d, lane);' % (r, r))
                 if r == 0:
                     B('  %s;' % TM(7))
-                if R['L1']:
+                if R['L1'] and not (r == 0 and self.h1d is not None):
                     B('  citw_lookup1d(wv, L[%d][1], g_out%d, lane);' % (r, r))
                 if r == 0:
                     B('  %s;' % TM(8))
@@ -565,6 +574,10 @@ class TeamGen(codegen.Gen):
                 for i in pre_x:
                     B('    g_f[0][stage][%d] = %s;' % (i, self.ref(self.xdot[i])))
                 B('  }')
+            if b != 0 and b == self.h1d:
+                B('  /* ---- the 1-D interpolation pass of round 1, taken over from wave 0 */')
+                B('  citw_iflag_wait(0, %s);' % SEQ)
+                B('  citw_lookup1d(0, L[0][1], g_out0, lane);')
             B('  %s;' % TM(0))
             B('  __syncthreads();   /* B1: look-up results (g_out0) and exchanged values (g_x) are visible to every wave */')
             after_b1[0] = True
