@@ -14,6 +14,9 @@ objdir = os.path.join(B.CSRC, 'build')
 objs = [os.path.join(objdir, u.replace('.hip', '.o')) for u in B.UNITS if u != 'rollout_team_nominal.hip']
 inc = 'gen/citation_nominal_team_%s.inc' % tag
 flags = list(B.FLAGS) + extra
+if os.environ.get('EXP_DROP_LICM'):            # A/B: let the machine LICM hoist the model's f64 literals out of the stage loop
+    i = flags.index('-disable-machine-licm')
+    del flags[i - 1:i + 1]
 if os.path.exists(os.path.join(B.CSRC, inc)):
     flags.append('-DCITW_TEAM_INC="%s"' % inc)
 obj = os.path.join(objdir, 'rollout_team_nominal_%s.o' % tag)
