@@ -318,7 +318,7 @@ class TeamGen(codegen.Gen):
           (K, V, [len(h) for h in self.have]))
         P(' * (the union has %d: the rest is recomputed), behind it: %s; %d values cross through g_x. */' %
           (len(set().union(*self.have)), [len(h) for h in self.phave], len(self.xslot)))
-        P('enum { citw_%s_team_WAVES = %d, citw_%s_team_NX = %d };' % (V, K, V, len(self.xslot)))
+        P('enum { citw_%s_team_WAVES = %d, citw_%s_team_NX = %d, citw_%s_team_BARRIERS = 2 };   /* workgroup barriers per evaluation and wavefront */' % (V, K, V, len(self.xslot), V))
 
         def function(b):
             body = []
