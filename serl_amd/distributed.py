@@ -55,3 +55,33 @@ def evaluate_pop_sharded(evaluate_local, pop, num_evals, device=None):
                 length_steps=g[..., 4].astype(np.int32), cost_steps=g[..., 5].astype(np.int32),
                 pop_fitness=pop_fitness, champion=int(np.argmax(pop_fitness)), worst=int(np.argmin(pop_fitness)),
                 block=(lo, hi))
+
+
+def gather_stored_episodes(staged_local, steps_local, cost_local, pop, world_size, rank):
+    """The stored episode of every member (agent.py:239: the last of its num_evals) on every rank.
+
+    With the population sharded by member, the transitions of member m's stored episode exist on its owner only, but the
+    SSNE epoch is replicated on all ranks (same host RNG streams, same index decisions) and proximal / safe mutation and
+    the distance-sorted crossover read the members' replay rings -- so the stored rows travel: ONE all_gather of
+    [ceil(pop / world), T, 20] f32 per generation (160 KB per member at 2 001 steps: 8 MB at pop = 50, 82 MB at pop = 512,
+    a few ms over xGMI), after which every rank appends all `pop` episodes to its rings in member order
+    (replay.store_episodes) and the rings are identical everywhere.
+
+    staged_local f32 [n_local, T, 20] (rows the rollout kernel wrote for this rank's members' stored episodes),
+    steps_local / cost_local int [n_local] -> (staged [pop, T, 20], steps [pop], cost_steps [pop])."""
+    per = (pop + world_size - 1) // world_size
+    n_local, T, W = staged_local.shape
+    dev = staged_local.device
+    buf = torch.zeros(per, T, W, dtype=staged_local.dtype, device=dev)
+    buf[:n_local] = staged_local
+    meta = torch.zeros(per, 2, dtype=torch.int64, device=dev)
+    meta[:n_local, 0] = torch.as_tensor(steps_local, dtype=torch.int64, device=dev)
+    meta[:n_local, 1] = torch.as_tensor(cost_local, dtype=torch.int64, device=dev)
+    if not dist.is_initialized():
+        return buf[:pop], meta[:pop, 0].cpu().numpy(), meta[:pop, 1].cpu().numpy()
+    bufs = [torch.empty_like(buf) for _ in range(world_size)]
+    metas = [torch.empty_like(meta) for _ in range(world_size)]
+    dist.all_gather(bufs, buf)
+    dist.all_gather(metas, meta)
+    allb, allm = torch.cat(bufs)[:pop], torch.cat(metas)[:pop]
+    return allb, allm[:, 0].cpu().numpy(), allm[:, 1].cpu().numpy()

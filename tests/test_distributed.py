@@ -26,12 +26,28 @@ def _local_eval(lo, hi):
                 length_t=sh(o['length_t']), length_steps=sh(o['length_steps']), cost_steps=sh(o['cost_steps']))
 
 
+def _stored(lo, hi):
+    """stand-in for the rows the rollout kernel stages for members lo..hi-1: deterministic per member"""
+    rs = [np.random.RandomState(100 + m) for m in range(lo, hi)]
+    steps = np.array([40 + 7 * m for m in range(lo, hi)], dtype=np.int64)
+    st = np.zeros((hi - lo, 90, 20), np.float32)
+    for j, r in enumerate(rs):
+        st[j, :steps[j]] = r.randn(steps[j], 20).astype(np.float32)
+        st[j, :steps[j], 19] = (r.rand(steps[j]) < 0.3)
+    cost = np.array([int(st[j, :steps[j], 19].sum()) for j in range(hi - lo)], dtype=np.int64)
+    return st, steps, cost
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from serl_amd import distributed as sd
     res = sd.evaluate_pop_sharded(_local_eval, POP, NE)
+    lo, hi = sd.member_block(POP, world, rank)
+    st, steps, cost = _stored(lo, hi)
+    gs, gsteps, gcost = sd.gather_stored_episodes(torch.from_numpy(st), steps, cost, POP, world, rank)
+    res['stored'] = (gs.numpy().copy(), gsteps.copy(), gcost.copy())
     q.put((rank, {k: (v if not isinstance(v, np.ndarray) else v.copy()) for k, v in res.items()}))
     dist.barrier()
     dist.destroy_process_group()
@@ -58,6 +74,16 @@ def test_two_rank_gather_equals_single_process():
         for k in ('fitness', 'returns', 'length_t', 'length_steps', 'cost_steps', 'pop_fitness'):
             np.testing.assert_array_equal(got[r][k], single[k], err_msg='rank %d %s' % (r, k))
         assert got[r]['champion'] == single['champion'] and got[r]['worst'] == single['worst']
+    # the stored episodes of ALL members on every rank (what the replicated SSNE epoch reads its replay rings from)
+    st, steps, cost = _stored(0, POP)
+    for r in (0, 1):
+        gs, gsteps, gcost = got[r]['stored']
+        np.testing.assert_array_equal(gs, st); np.testing.assert_array_equal(gsteps, steps); np.testing.assert_array_equal(gcost, cost)
+    from serl_amd.replay import DeviceReplay
+    rings = [DeviceReplay(64, 'cpu') for _ in range(POP)]
+    for m in range(POP):          # (CPU rings: plain torch indexing; on the GPU replay.store_episodes does this in one launch)
+        rings[m].append_rows(torch.from_numpy(got[0]['stored'][0][m, :steps[m]]))
+        assert len(rings[m]) == min(64, steps[m]) and rings[m].position == steps[m] % 64
 
 
 def test_member_blocks_cover_population():
