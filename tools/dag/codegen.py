@@ -182,13 +182,19 @@ class Gen:
             st.extend(build_dag.children(self.g, m))
         return out
 
+    @staticmethod
+    def two_mov_literal(bits):
+        """does materialising this f64 literal (given as its bit pattern) cost two 32-bit moves?  (inline constants and values
+        whose low dword is zero -- one v_mov_b64 with a 32-bit literal -- do not)"""
+        return (int(bits) & 0xffffffff) != 0 and symex.b2f(bits) not in (0.5, -0.5, 1.0, -1.0, 2.0, -2.0, 4.0, -4.0)
+
     # ---- expression of a node -----------------------------------------------------------------------
     def ref(self, n):
         g = self.g
         t = g.nodes[n]
         op = t[0]
         if op == 'cf':
-            if self.lds_consts and t[1] not in (0,):
+            if self.lds_consts and t[1] not in (0,) and (self.lds_consts != 2 or self.two_mov_literal(t[1])):
                 if t[1] not in self.kslot:
                     self.kslot[t[1]] = len(self.kslot)
                 return 'g_k[%d]' % self.kslot[t[1]]

@@ -637,6 +637,11 @@ class TeamGen(codegen.Gen):
             P('  if (wave == %d) return citw_%s_team_eval_w%d(stage, T, TICK);' % (b, V, b))
         P('  return citw_%s_team_eval_w%d(stage, T, TICK);' % (V, K - 1))
         P('}')
+        ks = sorted(self.kslot.items(), key=lambda kv: kv[1])
+        if ks:
+            P('#define CITW_TEAM_HAS_K 1')
+            P('enum { citw_%s_team_NK = %d };' % (V, len(ks)))
+            P('static __device__ const double citw_%s_team_k[%d] = {%s};' % (V, len(ks), ', '.join(hexf(v) for v, _ in ks)))
         self.libm_slot = dict(self.libm_slot_all)
         return '\n'.join(out) + '\n'
 
@@ -644,7 +649,7 @@ class TeamGen(codegen.Gen):
 def main():
     variants = [a for a in sys.argv[1:] if not a.startswith('--')] or ['nominal']
     for v in variants:
-        gen = TeamGen(v, hoist='--hoist-invariants' in sys.argv)
+        gen = TeamGen(v, hoist='--hoist-invariants' in sys.argv, lds_consts=int(os.environ.get('CITW_TEAM_LDS_CONSTS', 0)))
         text = gen.emit_team()
         suffix = next((a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--suffix=')), '')     # experiments: --suffix=_exp7
         path = os.path.join(build_dag.ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_team%s.inc' % (v, suffix))
