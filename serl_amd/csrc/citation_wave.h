@@ -30,6 +30,18 @@
 #define CITW_GROUP_LANES 64
 #endif
 #define CITW_LANE ((int)(threadIdx.x & (CITW_GROUP_LANES - 1)))
+// Rows of the generated TEAM code (gen/citation_<variant>_team.inc): one episode per workgroup -> row 0 of every shared
+// blackboard, wave q's libm results in g_m[q], exchanged values from g_x[0]; with two episodes per team (lane groups,
+// rollout_team_half.inc) the row is the lane group.
+#if CITW_GROUP_LANES == 64
+#define CITW_TROW 0
+#define CITW_MROW(q) (q)
+#define CITW_XOFF 0
+#else
+#define CITW_TROW ((int)((threadIdx.x >> 5) & 1))
+#define CITW_MROW(q) ((q) * 2 + CITW_TROW)
+#define CITW_XOFF (CITW_TROW * 128)
+#endif
 #ifndef CITW_SEARCH_BATCH
 #define CITW_SEARCH_BATCH 0     // 1 (team kernels): index-search compares in batches of eight; costs 44 VGPRs, which the one-wave kernels lack
 #endif
@@ -173,10 +185,12 @@ __shared__ unsigned long long g_tlastw[4];    // ... and for waves 2, 3 (barrier
 // All wavefronts of a workgroup are resident, so the poll cannot starve the writer; numbers only grow within an episode.
 static __device__ __forceinline__ void citw_flag_raise(int q, unsigned seq)
 {
+  seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);     // (two episodes per team: the first one's model clock counts for both)
   if ((threadIdx.x & 63) == 0) __hip_atomic_store(&g_flag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 static __device__ __forceinline__ void citw_flag_wait(int q, unsigned seq)
 {
+  seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);     // (two episodes per team: the first one's model clock counts for both)
   // "reached", not "equal": a producer can never be an evaluation ahead (barrier B2 separates evaluations), but a poll that
   // tolerates it cannot hang either
   while ((int)(__hip_atomic_load(&g_flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) __builtin_amdgcn_s_sleep(1);
@@ -185,10 +199,12 @@ static __device__ __forceinline__ void citw_flag_wait(int q, unsigned seq)
 // ... and a second set for the look-up inputs a helper wavefront computes for wave 0 (spread-input partitions)
 static __device__ __forceinline__ void citw_iflag_raise(int q, unsigned seq)
 {
+  seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);     // (two episodes per team: the first one's model clock counts for both)
   if ((threadIdx.x & 63) == 0) __hip_atomic_store(&g_iflag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 static __device__ __forceinline__ void citw_iflag_wait(int q, unsigned seq)
 {
+  seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);     // (two episodes per team: the first one's model clock counts for both)
   while ((int)(__hip_atomic_load(&g_iflag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) __builtin_amdgcn_s_sleep(1);
 }
 

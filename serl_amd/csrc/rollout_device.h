@@ -573,6 +573,92 @@ static __device__ __forceinline__ void serl_actor_forward_wave(const serl_rollou
   serl_actor_forward_wave(dd, w, obs, act_out, none);
 }
 
+static __device__ __forceinline__ float serl_half_shfl(float v, int srclane)
+{
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(srclane << 2, __float_as_int(v)));
+}
+
+// ---- two episodes per wavefront (rollout_half.inc, rollout_team_half.inc) -------------------------------------------------
+// Actor forward for H = 32, one episode per half-wavefront: lane gl of a half owns hidden row gl of ITS episode's member.
+// Same arithmetic as serl_actor_forward_small<32> (include/serl_amd.h): dot products as four interleaved fma partial sums
+// over ascending columns, LayerNorm sums as a pairwise tree per 16 rows, the two blocks added in order.  Where the
+// one-episode kernels broadcast the previous layer with v_readlane (a wave-uniform SGPR), the two episodes here need two
+// different values per column: the layer goes through an LDS row per episode and comes back as eight 16-byte broadcast reads.
+template <class Sync>
+static __device__ void serl_actor_forward_half32(const serl_rollout_desc &dd, const float *w_generic, float *hx /* this lane's episode row, 32 floats of LDS */,
+                                                 const float obs[7], float act_out[3], Sync &sync)
+{
+  constexpr int H = 32;
+  const int L = __builtin_amdgcn_readfirstlane(dd.num_layers), act = __builtin_amdgcn_readfirstlane(dd.activation);
+  serl_gptr w = (serl_gptr)w_generic;                  // this lane's member
+  const int lane = threadIdx.x & 63, gl = lane & 31, base = lane & 32;
+  const int io = gl < 3 ? gl : 2;
+  constexpr size_t lstride = (size_t)H * H + 3 * (size_t)H;
+  serl_gptr hid = w + (size_t)H * 7 + H, outl = hid + (size_t)L * lstride;
+  float nrow[H], nbi, ngm = 0.0f, nbt = 0.0f;
+  auto issue = [&](int l) {
+    serl_gptr row = l < L ? hid + (size_t)l * lstride + (size_t)gl * H : outl + (size_t)io * H;
+#pragma unroll
+    for (int q = 0; q < H / 4; ++q) {
+      const serl_v4f v = *(serl_gptr4)(row + 4 * q);
+      nrow[4 * q] = v.x; nrow[4 * q + 1] = v.y; nrow[4 * q + 2] = v.z; nrow[4 * q + 3] = v.w;
+    }
+    if (l < L) {
+      serl_gptr bl = hid + (size_t)l * lstride + (size_t)H * H;
+      nbi = bl[gl]; ngm = bl[H + gl]; nbt = bl[2 * H + gl];
+    } else {
+      nbi = (outl + (size_t)3 * H)[io];
+    }
+  };
+  issue(0);
+  float h;
+  {
+    serl_gptr W = w + (size_t)gl * 7, b = w + (size_t)H * 7;
+    float acc = b[gl], w0[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) w0[j] = W[j];
+    acc = serl_dot7(acc, w0, obs);
+    h = serl_act(acc, act);
+  }
+  sync(0, L + 2);
+  for (int l = 0; l <= L; ++l) {
+    float row[H];
+#pragma unroll
+    for (int j = 0; j < H; ++j) row[j] = nrow[j];
+    float acc = nbi;
+    const float gm = ngm, bt = nbt;
+    if (l < L) issue(l + 1);
+    // previous layer -> every lane of the episode (LDS operations of a wavefront complete in order)
+    hx[gl] = h;
+    float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < H / 4; ++q) {
+      const serl_v4f hv = *reinterpret_cast<const serl_v4f *>(hx + 4 * q);
+      p[0] = __builtin_fmaf(row[4 * q], hv.x, p[0]);
+      p[1] = __builtin_fmaf(row[4 * q + 1], hv.y, p[1]);
+      p[2] = __builtin_fmaf(row[4 * q + 2], hv.z, p[2]);
+      p[3] = __builtin_fmaf(row[4 * q + 3], hv.w, p[3]);
+    }
+    acc = acc + ((p[0] + p[1]) + (p[2] + p[3]));
+    if (l < L) {
+      const float t1 = serl_row16_tree(acc);
+      float mean = serl_half_shfl(t1, base) + serl_half_shfl(t1, base + 16);
+      mean = mean / (float)H;
+      const float d = acc - mean, dd2 = d * d;
+      const float t2 = serl_row16_tree(dd2);
+      const float var = serl_half_shfl(t2, base) + serl_half_shfl(t2, base + 16);
+      const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
+      h = serl_act(gm * d / den + bt, act);
+    } else {
+      const float t = det_tanhf(acc);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) act_out[i] = serl_half_shfl(t, base + i);
+    }
+    sync(l + 1, L + 2);
+  }
+}
+
+
 template <class Sync>
 static __device__ __forceinline__ void serl_actor_forward(const serl_rollout_desc &dd, const float *w, const float obs[7],
                                                           float act_out[3], Sync &sync)

@@ -44,6 +44,31 @@ static void serl_launch_rollout_half(int code, const RolloutArgs &a, int grid, h
   }
 }
 
+// two episodes per team (rollout_team_half.inc): between CUs and 4 x CUs episodes
+#define SERL_DECL_TEAM2(v) void serl_launch_rollout_team2_##v(const RolloutArgs &a, int grid, hipStream_t stream);
+SERL_DECL_TEAM2(nominal) SERL_DECL_TEAM2(ice) SERL_DECL_TEAM2(cg_timed) SERL_DECL_TEAM2(gust) SERL_DECL_TEAM2(test)
+
+static void serl_launch_rollout_team2(int code, const RolloutArgs &a, int grid, hipStream_t stream)
+{
+  switch (code) {
+    case SERL_DYN_NOMINAL: serl_launch_rollout_team2_nominal(a, grid, stream); break;
+    case SERL_DYN_ICE: serl_launch_rollout_team2_ice(a, grid, stream); break;
+    case SERL_DYN_CG_TIMED: serl_launch_rollout_team2_cg_timed(a, grid, stream); break;
+    case SERL_DYN_GUST: serl_launch_rollout_team2_gust(a, grid, stream); break;
+    default: serl_launch_rollout_team2_test(a, grid, stream); break;
+  }
+}
+
+// A team carrying two episodes needs ~1.15 x the time of a team carrying one, and one team fits a CU: up to 2 x CUs
+// episodes run in one round of workgroups (~25 us per env step against 57 of the one-wavefront kernel), up to 4 x CUs in
+// two (~50 against 57 - 61).  H = 32 only.  SERL_TEAM2=0 / 1 overrides.
+static bool serl_use_team2(const serl_ctx *c, const serl_rollout_desc *d, int episodes)
+{
+  if (d->hidden != 32) return false;
+  if (c->env_team2 >= 0) return c->env_team2 != 0;
+  return episodes > c->num_cus && episodes <= 4 * c->num_cus;
+}
+
 // The one-wavefront-per-episode kernel runs up to 4 x CUs episodes at once (one per SIMD); beyond that the launch needs a
 // second round of wavefronts, and packing two episodes into a wavefront (1.1 x the time per env step) is the better deal.
 // H = 32 only (the lane group of an episode holds one hidden row per lane).  SERL_HALF=0 / 1 overrides.
@@ -140,6 +165,7 @@ static void serl_ctx_read_env(serl_ctx *c)
   c->env_team = (e = getenv("SERL_TEAM")) ? atoi(e) : -1;
   c->env_waves_per_block = (e = getenv("SERL_WAVES_PER_BLOCK")) ? atoi(e) : -1;
   c->env_half = (e = getenv("SERL_HALF")) ? atoi(e) : -1;
+  c->env_team2 = (e = getenv("SERL_TEAM2")) ? atoi(e) : -1;
   c->env_profile = getenv("SERL_PROFILE") != nullptr;
 }
 
@@ -256,6 +282,16 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     a.block = 128;
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
     serl_launch_rollout_team(s.code, a, d->n_episodes, stream);
+    HIP_TRY(hipGetLastError());
+    if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
+    c->timed = timed;
+    return SERL_OK;
+  }
+  if (lanes <= 0 && serl_has_wave_kernel(s.code) && !(c->env_half > 0) && serl_use_team2(c, d, together)) {
+    a.lanes = 1;
+    a.block = 512;
+    if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
+    serl_launch_rollout_team2(s.code, a, (d->n_episodes + 1) / 2, stream);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = timed;

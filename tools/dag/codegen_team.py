@@ -626,6 +626,14 @@ class TeamGen(codegen.Gen):
             text = text.replace('g_in[wv]', 'g_in[%d]' % b).replace('g_m[wv]', 'g_m[%d]' % b)
             text = text.replace('g_inv[wv]', 'g_inv[%d]' % b).replace('g_out%d[wv]' % len(self.rounds), 'g_out%d[%d]' % (len(self.rounds), b))
             text = text.replace('[wv]', '[0]').replace('(wv, ', '(%d, ' % b)
+            # rows as macros (citation_wave.h): CITW_TROW = the episode's row of the shared blackboards (0; the lane group in the
+            # two-episodes-per-team kernels), CITW_MROW(q) = wave q's libm-result row, CITW_XOFF = base of the episode's g_x slots
+            import re
+            text = re.sub(r'\b(g_xs|g_out0|g_out1|g_in|g_dw|g_cmd|g_f)\[0\]', r'\1[CITW_TROW]', text)
+            text = re.sub(r'\bg_m\[(\d+)\]', r'g_m[CITW_MROW(\1)]', text)
+            text = re.sub(r'\bg_x\[(\d+)\]', r'g_x[CITW_XOFF + \1]', text)
+            text = re.sub(r'\b(citw_search<[^>]*>|citw_lookup2d|citw_lookup1d)\(0, ', r'\1(CITW_TROW, ', text)
+            text = text.replace('const int lane = threadIdx.x & 63;', 'const int lane = CITW_LANE;')
             return text
 
         for b in range(K - 1, -1, -1):
