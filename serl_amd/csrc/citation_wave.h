@@ -37,10 +37,12 @@
 #define CITW_TROW 0
 #define CITW_MROW(q) (q)
 #define CITW_XOFF 0
+#define CITW_GROUPS 1
 #else
-#define CITW_TROW ((int)((threadIdx.x >> 5) & 1))
-#define CITW_MROW(q) ((q) * 2 + CITW_TROW)
-#define CITW_XOFF (CITW_TROW * 128)
+#define CITW_GROUPS (64 / CITW_GROUP_LANES)                      // 2 or 4 episodes per wavefront
+#define CITW_TROW ((int)((threadIdx.x & 63) / CITW_GROUP_LANES))
+#define CITW_MROW(q) ((q) * CITW_GROUPS + CITW_TROW)
+#define CITW_XOFF (CITW_TROW * (256 / CITW_GROUPS))
 #endif
 #ifndef CITW_SEARCH_BATCH
 #define CITW_SEARCH_BATCH 0     // 1 (team kernels): index-search compares in batches of eight; costs 44 VGPRs, which the one-wave kernels lack
@@ -425,6 +427,7 @@ static __device__ __forceinline__ double citw_ode5_combine(int st, const double 
 // the model evaluation reads all 19 as wave-uniform LDS loads from g_xs.
 struct CitwState {
   double xi;          // this lane's own state component (lane < 19); the wave-uniform copy lives in g_xs
+  double xj;          // 16-lane groups only: state component lane + 16 (lanes 0..2)
   double t;           // model time
   unsigned tick;      // clockTick0
 };

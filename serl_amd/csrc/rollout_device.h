@@ -659,6 +659,97 @@ static __device__ void serl_actor_forward_half32(const serl_rollout_desc &dd, co
 }
 
 
+// ---- four episodes per wavefront (rollout_team_half.inc with CITW_GROUP_LANES == 16) --------------------------------------
+// Actor forward for H = 32, one episode per 16 lanes: lane gl of a group owns hidden rows gl and gl + 16 of its episode's
+// member.  Same arithmetic again: the LayerNorm's two 16-row blocks are this lane group's first and second rows, each
+// summed as the pairwise DPP tree, added in order.
+template <class Sync>
+static __device__ void serl_actor_forward_quarter32(const serl_rollout_desc &dd, const float *w_generic, float *hx /* this lane's episode row, 32 floats of LDS */,
+                                                    const float obs[7], float act_out[3], Sync &sync)
+{
+  constexpr int H = 32;
+  const int L = __builtin_amdgcn_readfirstlane(dd.num_layers), act = __builtin_amdgcn_readfirstlane(dd.activation);
+  serl_gptr w = (serl_gptr)w_generic;                  // this lane's member
+  const int lane = threadIdx.x & 63, gl = lane & 15, base = lane & 48;
+  const int io = gl < 3 ? gl : 2;
+  constexpr size_t lstride = (size_t)H * H + 3 * (size_t)H;
+  serl_gptr hid = w + (size_t)H * 7 + H, outl = hid + (size_t)L * lstride;
+  float nrow[2][H], nbi[2], ngm[2] = {0.0f, 0.0f}, nbt[2] = {0.0f, 0.0f};
+  auto issue = [&](int l) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (l >= L && r == 1) break;                     // the output layer has three rows: first slot only
+      serl_gptr row = l < L ? hid + (size_t)l * lstride + (size_t)(gl + 16 * r) * H : outl + (size_t)io * H;
+#pragma unroll
+      for (int q = 0; q < H / 4; ++q) {
+        const serl_v4f v = *(serl_gptr4)(row + 4 * q);
+        nrow[r][4 * q] = v.x; nrow[r][4 * q + 1] = v.y; nrow[r][4 * q + 2] = v.z; nrow[r][4 * q + 3] = v.w;
+      }
+      if (l < L) {
+        serl_gptr bl = hid + (size_t)l * lstride + (size_t)H * H;
+        nbi[r] = bl[gl + 16 * r]; ngm[r] = bl[H + gl + 16 * r]; nbt[r] = bl[2 * H + gl + 16 * r];
+      } else {
+        nbi[r] = (outl + (size_t)3 * H)[io];
+      }
+    }
+  };
+  issue(0);
+  float h[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    serl_gptr W = w + (size_t)(gl + 16 * r) * 7, b = w + (size_t)H * 7;
+    float acc = b[gl + 16 * r], w0[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) w0[j] = W[j];
+    acc = serl_dot7(acc, w0, obs);
+    h[r] = serl_act(acc, act);
+  }
+  sync(0, L + 2);
+  for (int l = 0; l <= L; ++l) {
+    float row[2][H], acc[2], gm[2], bt[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+      for (int j = 0; j < H; ++j) row[r][j] = nrow[r][j];
+      acc[r] = nbi[r]; gm[r] = ngm[r]; bt[r] = nbt[r];
+    }
+    if (l < L) issue(l + 1);
+    // previous layer -> every lane of the episode (LDS operations of a wavefront complete in order)
+    hx[gl] = h[0]; hx[gl + 16] = h[1];
+    float p[2][4] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+#pragma unroll
+    for (int q = 0; q < H / 4; ++q) {
+      const serl_v4f hv = *reinterpret_cast<const serl_v4f *>(hx + 4 * q);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        p[r][0] = __builtin_fmaf(row[r][4 * q], hv.x, p[r][0]);
+        p[r][1] = __builtin_fmaf(row[r][4 * q + 1], hv.y, p[r][1]);
+        p[r][2] = __builtin_fmaf(row[r][4 * q + 2], hv.z, p[r][2]);
+        p[r][3] = __builtin_fmaf(row[r][4 * q + 3], hv.w, p[r][3]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) acc[r] = acc[r] + ((p[r][0] + p[r][1]) + (p[r][2] + p[r][3]));
+    if (l < L) {
+      const float ta = serl_row16_tree(acc[0]), tb = serl_row16_tree(acc[1]);
+      float mean = serl_half_shfl(ta, base) + serl_half_shfl(tb, base);
+      mean = mean / (float)H;
+      const float d0 = acc[0] - mean, d1 = acc[1] - mean;
+      const float ua = serl_row16_tree(d0 * d0), ub = serl_row16_tree(d1 * d1);
+      const float var = serl_half_shfl(ua, base) + serl_half_shfl(ub, base);
+      const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
+      h[0] = serl_act(gm[0] * d0 / den + bt[0], act);
+      h[1] = serl_act(gm[1] * d1 / den + bt[1], act);
+    } else {
+      const float t = det_tanhf(acc[0]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) act_out[i] = serl_half_shfl(t, base + i);
+    }
+    sync(l + 1, L + 2);
+  }
+}
+
+
 template <class Sync>
 static __device__ __forceinline__ void serl_actor_forward(const serl_rollout_desc &dd, const float *w, const float obs[7],
                                                           float act_out[3], Sync &sync)

@@ -1,0 +1,15 @@
+// rollout_team4_gust.hip -- four episodes per team (rollout_team.inc + rollout_team_half.inc, lane groups of 16) for the 'gust'
+// dynamics code variant: between 2 x CUs and 4 x CUs episodes per launch, SERL50 actor shape (H = 32).
+#define CITW_SEARCH_BATCH 1
+#define CITW_GROUP_LANES 16
+#define CITW_MAX_WAVES 4          // blackboard rows: one per episode of the team
+#define CITW_M_ROWS 32            // libm result rows: one per (team wavefront, episode)
+#define CITW_OUT2_ROWS 1
+#define CITW_INV_SLOTS 8
+#include "citation_wave.h"
+#include "rollout_device.h"
+#include "gen/citation_gust_wave.inc"   // look-up descriptor tables (shared with the one-wave kernels)
+#include "gen/citation_gust_team.inc"
+#define VARIANT gust
+#include "rollout_team.inc"
+#undef VARIANT

@@ -44,29 +44,35 @@ static void serl_launch_rollout_half(int code, const RolloutArgs &a, int grid, h
   }
 }
 
-// two episodes per team (rollout_team_half.inc): between CUs and 4 x CUs episodes
-#define SERL_DECL_TEAM2(v) void serl_launch_rollout_team2_##v(const RolloutArgs &a, int grid, hipStream_t stream);
-SERL_DECL_TEAM2(nominal) SERL_DECL_TEAM2(ice) SERL_DECL_TEAM2(cg_timed) SERL_DECL_TEAM2(gust) SERL_DECL_TEAM2(test)
+// two / four episodes per team (rollout_team_half.inc): between CUs and 4 x CUs episodes
+#define SERL_DECL_TEAMG(v) void serl_launch_rollout_team2_##v(const RolloutArgs &a, int grid, hipStream_t stream); \
+                           void serl_launch_rollout_team4_##v(const RolloutArgs &a, int grid, hipStream_t stream);
+SERL_DECL_TEAMG(nominal) SERL_DECL_TEAMG(ice) SERL_DECL_TEAMG(cg_timed) SERL_DECL_TEAMG(gust) SERL_DECL_TEAMG(test)
 
-static void serl_launch_rollout_team2(int code, const RolloutArgs &a, int grid, hipStream_t stream)
+static void serl_launch_rollout_teamg(int code, int groups, const RolloutArgs &a, int grid, hipStream_t stream)
 {
+#define SERL_TEAMG_CASE(v) (groups == 4 ? serl_launch_rollout_team4_##v(a, grid, stream) : serl_launch_rollout_team2_##v(a, grid, stream))
   switch (code) {
-    case SERL_DYN_NOMINAL: serl_launch_rollout_team2_nominal(a, grid, stream); break;
-    case SERL_DYN_ICE: serl_launch_rollout_team2_ice(a, grid, stream); break;
-    case SERL_DYN_CG_TIMED: serl_launch_rollout_team2_cg_timed(a, grid, stream); break;
-    case SERL_DYN_GUST: serl_launch_rollout_team2_gust(a, grid, stream); break;
-    default: serl_launch_rollout_team2_test(a, grid, stream); break;
+    case SERL_DYN_NOMINAL: SERL_TEAMG_CASE(nominal); break;
+    case SERL_DYN_ICE: SERL_TEAMG_CASE(ice); break;
+    case SERL_DYN_CG_TIMED: SERL_TEAMG_CASE(cg_timed); break;
+    case SERL_DYN_GUST: SERL_TEAMG_CASE(gust); break;
+    default: SERL_TEAMG_CASE(test); break;
   }
+#undef SERL_TEAMG_CASE
 }
 
-// A team carrying two episodes needs ~1.15 x the time of a team carrying one, and one team fits a CU: up to 2 x CUs
-// episodes run in one round of workgroups (~25 us per env step against 57 of the one-wavefront kernel), up to 4 x CUs in
-// two (~50 against 57 - 61).  H = 32 only.  SERL_TEAM2=0 / 1 overrides.
-static bool serl_use_team2(const serl_ctx *c, const serl_rollout_desc *d, int episodes)
+// Episodes per team, 0 = use another kernel.  Measured per env step: 21.6 us with one episode per team, 24.7 with two,
+// 30.8 with four (the scalar glue is paid once for all lane groups; only the lane-parallel passes multiply), and one team
+// fits a CU -- so up to 2 x CUs episodes run two per team and up to 4 x CUs four per team, in ONE round of workgroups,
+// against 57 us of the one-wavefront kernel (1 023 episodes: 33.2 M env-steps/s against 16).  H = 32 only.
+// SERL_TEAM2=0 / 2 / 4 overrides (1 = 2).
+static int serl_use_teamg(const serl_ctx *c, const serl_rollout_desc *d, int episodes)
 {
-  if (d->hidden != 32) return false;
-  if (c->env_team2 >= 0) return c->env_team2 != 0;
-  return episodes > c->num_cus && episodes <= 4 * c->num_cus;
+  if (d->hidden != 32) return 0;
+  if (c->env_team2 >= 0) return c->env_team2 == 0 ? 0 : (c->env_team2 == 4 ? 4 : 2);
+  if (episodes <= c->num_cus || episodes > 4 * c->num_cus) return 0;
+  return episodes <= 2 * c->num_cus ? 2 : 4;
 }
 
 // The one-wavefront-per-episode kernel runs up to 4 x CUs episodes at once (one per SIMD); beyond that the launch needs a
@@ -287,11 +293,12 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     c->timed = timed;
     return SERL_OK;
   }
-  if (lanes <= 0 && serl_has_wave_kernel(s.code) && !(c->env_half > 0) && serl_use_team2(c, d, together)) {
+  const int teamg = (lanes <= 0 && serl_has_wave_kernel(s.code) && !(c->env_half > 0)) ? serl_use_teamg(c, d, together) : 0;
+  if (teamg) {
     a.lanes = 1;
     a.block = 512;
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
-    serl_launch_rollout_team2(s.code, a, (d->n_episodes + 1) / 2, stream);
+    serl_launch_rollout_teamg(s.code, teamg, a, (d->n_episodes + teamg - 1) / teamg, stream);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = timed;

@@ -470,17 +470,17 @@ class TeamGen(codegen.Gen):
                             B('  citw_flag_wait(%d, %s);   /* the input(s) wave %d computes are in g_in[0] */' % (self.P, SEQ, self.P))
                             waited.add(self.P)
                         B('  %s;' % TM(9))
-                B('  citw_search<%d>(wv, S[%d], lane);' % (R['maxn'], r))
+                B('  citw_search<%d, %d>(wv, S[%d], lane);' % (R['maxn'], len(R['searches']), r))
                 if r == 0 and self.h1d is not None:
                     B('  citw_iflag_raise(0, %s);   /* interval indices are in g_sidx[0]: wave %d runs the 1-D pass beside the 2-D pass */' % (SEQ, self.h1d))
                 if r == 0:
                     B('  %s;' % TM(6))
                 if R['L2']:
-                    B('  citw_lookup2d(wv, L[%d][0], g_out%d, lane);' % (r, r))
+                    B('  citw_lookup2d<%d>(wv, L[%d][0], g_out%d, lane);' % (len(R['L2']), r, r))
                 if r == 0:
                     B('  %s;' % TM(7))
                 if R['L1'] and not (r == 0 and self.h1d is not None):
-                    B('  citw_lookup1d(wv, L[%d][1], g_out%d, lane);' % (r, r))
+                    B('  citw_lookup1d<%d>(wv, L[%d][1], g_out%d, lane);' % (len(R['L1']), r, r))
                 if r == 0:
                     B('  %s;' % TM(8))
 
@@ -577,7 +577,7 @@ class TeamGen(codegen.Gen):
             if b != 0 and b == self.h1d:
                 B('  /* ---- the 1-D interpolation pass of round 1, taken over from wave 0 */')
                 B('  citw_iflag_wait(0, %s);' % SEQ)
-                B('  citw_lookup1d(0, L[0][1], g_out0, lane);')
+                B('  citw_lookup1d<%d>(0, L[0][1], g_out0, lane);' % len(self.rounds[0]['L1']))
             B('  %s;' % TM(0))
             B('  __syncthreads();   /* B1: look-up results (g_out0) and exchanged values (g_x) are visible to every wave */')
             after_b1[0] = True
@@ -632,7 +632,7 @@ class TeamGen(codegen.Gen):
             text = re.sub(r'\b(g_xs|g_out0|g_out1|g_in|g_dw|g_cmd|g_f)\[0\]', r'\1[CITW_TROW]', text)
             text = re.sub(r'\bg_m\[(\d+)\]', r'g_m[CITW_MROW(\1)]', text)
             text = re.sub(r'\bg_x\[(\d+)\]', r'g_x[CITW_XOFF + \1]', text)
-            text = re.sub(r'\b(citw_search<[^>]*>|citw_lookup2d|citw_lookup1d)\(0, ', r'\1(CITW_TROW, ', text)
+            text = re.sub(r'\b(citw_search<[^>]*>|citw_lookup2d<\d+>|citw_lookup1d<\d+>)\(0, ', r'\1(CITW_TROW, ', text)
             text = text.replace('const int lane = threadIdx.x & 63;', 'const int lane = CITW_LANE;')
             return text
 
