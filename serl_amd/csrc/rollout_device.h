@@ -23,6 +23,7 @@ struct RolloutArgs {
   int32_t lanes;                      // active lanes per 64-lane wavefront
   int32_t block;                      // threads per workgroup (64 x wavefronts sharing one LDS table copy)
   unsigned long long *prof;           // optional [4] cycle counters of wave 0 / block 0: actor, dynamics, env, steps
+  int32_t e0, e_end;                  // team kernels: the episodes [e0, e_end) of the descriptor this launch runs (serl_rollout splits large launches)
 };
 
 #define DET_FN __device__ __forceinline__

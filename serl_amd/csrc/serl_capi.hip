@@ -75,6 +75,16 @@ static int serl_use_teamg(const serl_ctx *c, const serl_rollout_desc *d, int epi
   return episodes <= 2 * c->num_cus ? 2 : 4;
 }
 
+// Beyond 4 x CUs episodes the team kernels still win when the launch has the GPU to itself: 4 x CUs episodes per 30.8 us
+// is the rate of the two-episodes-per-wavefront kernel (8 x CUs per 62.9 us) at half the granularity, and the remainder runs
+// at the rate of its own size class.  Side-by-side launches (concurrent_episodes > 0) keep the half kernel: a team needs a
+// whole CU.  H = 32 only; SERL_TEAM2 / SERL_HALF overrides switch it off.
+static bool serl_use_team_rounds(const serl_ctx *c, const serl_rollout_desc *d, int episodes)
+{
+  if (d->hidden != 32 || c->env_team2 >= 0 || c->env_half >= 0 || c->env_team == 0) return false;
+  return d->concurrent_episodes <= 0 && episodes > 4 * c->num_cus;
+}
+
 // The one-wavefront-per-episode kernel runs up to 4 x CUs episodes at once (one per SIMD); beyond that the launch needs a
 // second round of wavefronts, and packing two episodes into a wavefront (1.1 x the time per env step) is the better deal.
 // H = 32 only (the lane group of an episode holds one hidden row per lane).  SERL_HALF=0 / 1 overrides.
@@ -283,6 +293,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   // not recorded for them (an event in flight on one stream must not be re-recorded on another)
   const bool timed = d->concurrent_episodes <= 0;
   const int together = d->n_episodes + (d->concurrent_episodes > 0 ? d->concurrent_episodes : 0);   // episodes sharing the GPU
+  a.e0 = 0; a.e_end = d->n_episodes;
   if (lanes <= 0 && serl_use_team(c, s.code, together)) {
     a.lanes = 1;
     a.block = 128;
@@ -300,6 +311,27 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
     serl_launch_rollout_teamg(s.code, teamg, a, (d->n_episodes + teamg - 1) / teamg, stream);
     HIP_TRY(hipGetLastError());
+    if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
+    c->timed = timed;
+    return SERL_OK;
+  }
+  if (lanes <= 0 && serl_has_wave_kernel(s.code) && serl_use_team_rounds(c, d, together)) {
+    // more than 4 x CUs episodes, alone on the GPU: rounds of 4 x CUs episodes (four per team, every CU busy), then the rest
+    // with whichever team kernel suits its count -- 4 x CUs + 2 episodes cost 30.8 + 21.6 us per env step, not 62.9
+    a.lanes = 1;
+    a.block = 512;
+    if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
+    const int full = 4 * c->num_cus;
+    for (int e0 = 0; e0 < d->n_episodes; e0 += full) {
+      const int n = d->n_episodes - e0 < full ? d->n_episodes - e0 : full;
+      a.e0 = e0; a.e_end = e0 + n;
+      if (n <= c->num_cus) serl_launch_rollout_team(s.code, a, n, stream);
+      else {
+        const int g = n <= 2 * c->num_cus ? 2 : 4;
+        serl_launch_rollout_teamg(s.code, g, a, (n + g - 1) / g, stream);
+      }
+      HIP_TRY(hipGetLastError());
+    }
     if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = timed;
     return SERL_OK;
