@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SERL_ABI_VERSION 4
+#define SERL_ABI_VERSION 5
 
 enum serl_error {
   SERL_OK = 0,
@@ -146,11 +146,31 @@ typedef struct serl_rollout_desc {
   double *states;                   /* env.x per step:       [n_episodes][max_steps][12] */
   double *rewards;                  /* reward per step:      [n_episodes][max_steps] */
   float *transitions;               /* (obs7,a3,next_obs7,r,done,cost) f32 x20 per step:
-                                       [n_episodes][max_steps][20]  (base/core/agent.py:101-112) */
+                                       [n_episodes][max_steps][20]  (base/core/agent.py:101-112); other env
+                                       configurations: 2 S + A + 3 floats per step, see env_config */
   /* -- reference generation in the kernel (NULL = table mode: `ref` is read) */
   const serl_ref_spec *ref_spec;    /* [n_episodes] (ref_spec_stride 1) or one shared spec (stride 0); `ref` may be NULL */
   int64_t ref_spec_stride;
+  /* -- env configuration (CitationEnv(configuration, mode), envs/phlabenv.py:84-97,174-176,205-220,377-380,415-428,
+   *    446-470); zeros = the attitude task every BASELINE configuration uses.
+   *      env_config   SERL_ENV_ATTITUDE   A = 3 actions (de da dr), observed states x[0 1 2 4] (p q r alpha)
+   *                   SERL_ENV_SYMMETRIC  A = 1 (de; one reference: theta), observed state x[1] (q)
+   *                   SERL_ENV_FULL       A = 3, observed states x[0..9]
+   *      incremental  the action is an actuator RATE: scaled to +-25 deg/s instead of +-10 deg, u = last_u + scaled * dt
+   *                   (last_u = 0 at reset), and last_u is part of the observation
+   *    observation = [error (A), observed states, last_u (A, incremental only)]; state_dim must equal its length and
+   *    action_dim must equal A.  reward = -sum_i<A |clip(scaler_i * error_i, -1, 1)| / A.  The per-episode tables keep
+   *    their 3-column layouts (ref, err0, action_noise, actions: the first A columns are used / written, the others
+   *    are 0); a transition row is (obs S, action A, next_obs S, reward, done, cost) = 2 S + A + 3 floats.
+   *    Configurations other than the default run on the one-wavefront-per-episode kernel. */
+  int32_t env_config;
+  int32_t incremental;
 } serl_rollout_desc;
+
+enum serl_env_config { SERL_ENV_ATTITUDE = 0, SERL_ENV_SYMMETRIC = 1, SERL_ENV_FULL = 2 };
+/* length of the observation of a configuration (0 = invalid) and its number of actions */
+int serl_env_state_dim(int env_config, int incremental);
+int serl_env_action_dim(int env_config);
 
 int serl_abi_version(void);
 /* number of f32 parameters of an actor: H*S+H + L*(H*H+3H) + A*H+A */

@@ -25,7 +25,8 @@ class RolloutDesc(ctypes.Structure):
                 ('concurrent_episodes', ctypes.c_int32), ('pad_', ctypes.c_int32),
                 ('fitness', _D), ('length_steps', _I), ('length_t', _D), ('cost_steps', _I),
                 ('actions', _D), ('states', _D), ('rewards', _D), ('transitions', _F),
-                ('ref_spec', ctypes.c_void_p), ('ref_spec_stride', ctypes.c_int64)]
+                ('ref_spec', ctypes.c_void_p), ('ref_spec_stride', ctypes.c_int64),
+                ('env_config', ctypes.c_int32), ('incremental', ctypes.c_int32)]
 
 
 def _n_steps_for(t_max, dt=0.01):
@@ -66,12 +67,14 @@ def make_build_desc(build):
 
 
 def rollout(weights, net, member_of_episode, ref, *, build='h2000_v90', faults=None, err0=None,
-            tick0=None, action_noise=None, noise_row=None, sensor_noise=None, sensor_row=None, t_max=80.0, traces=False, transitions=False, threads=1):
+            tick0=None, action_noise=None, noise_row=None, sensor_noise=None, sensor_row=None, t_max=80.0, traces=False, transitions=False, threads=1,
+            env_config=0, incremental=False):
     """Run episodes on the CPU oracle.
 
     weights [n_members, P] f32 (packed state_dict order); net = dict(state_dim, action_dim, hidden,
     num_layers, activation); ref [n_ep, T, 3] or [T, 3] f64 radians; faults: list of fault names or
-    [n_ep, 8] rows.  Returns dict of numpy arrays."""
+    [n_ep, 8] rows; env_config 0 / 1 / 2 = attitude / symmetric / full, incremental = rate control
+    (envs/phlabenv.py:84-97,174-176).  Returns dict of numpy arrays."""
     L = _dyn.lib()
     L.serl_oracle_rollout.argtypes = [ctypes.POINTER(BuildDesc), ctypes.POINTER(RolloutDesc), ctypes.c_int]
     L.serl_oracle_rollout.restype = ctypes.c_int
@@ -97,7 +100,7 @@ def rollout(weights, net, member_of_episode, ref, *, build='h2000_v90', faults=N
                     n_members=weights.shape[0], weights=weights.ctypes.data_as(_F), weight_stride=weights.shape[1],
                     n_episodes=n_ep, build_slot=0, member_of_episode=moe.ctypes.data_as(_I),
                     ref=ref.ctypes.data_as(_D), ref_stride=0 if shared else T * 3, t_max=float(t_max),
-                    max_steps=T, lanes_per_wave=0)
+                    max_steps=T, lanes_per_wave=0, env_config=int(env_config), incremental=int(bool(incremental)))
     keep = [weights, moe, ref]
     if spec is not None:
         d.ref = None
@@ -141,7 +144,7 @@ def rollout(weights, net, member_of_episode, ref, *, build='h2000_v90', faults=N
         d.actions = out['actions'].ctypes.data_as(_D); d.states = out['states'].ctypes.data_as(_D)
         d.rewards = out['rewards'].ctypes.data_as(_D)
     if transitions:
-        out['transitions'] = np.zeros((n_ep, T, 20), np.float32)
+        out['transitions'] = np.zeros((n_ep, T, 2 * net['state_dim'] + net['action_dim'] + 3), np.float32)
         d.transitions = out['transitions'].ctypes.data_as(_F)
     bd = make_build_desc(build)
     rc = L.serl_oracle_rollout(ctypes.byref(bd), ctypes.byref(d), int(threads))

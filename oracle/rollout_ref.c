@@ -199,14 +199,38 @@ static void add_sensor_noise(double *x, const double *sn)
   x[0] += sn[0]; x[1] += sn[1]; x[2] += sn[2]; x[4] += sn[3]; x[5] += sn[4]; x[6] += sn[5]; x[7] += sn[6];
 }
 
+/* envs/phlabenv.py:84-97 (obs_idx per configuration), :213-220 (n_obs), :415-428 / :462-468 (observation) */
+int serl_env_action_dim(int env_config) { return env_config == SERL_ENV_SYMMETRIC ? 1 : 3; }
+int serl_env_state_dim(int env_config, int incremental)
+{
+  if (env_config < 0 || env_config > 2) return 0;
+  const int A = serl_env_action_dim(env_config);
+  const int nx = env_config == SERL_ENV_ATTITUDE ? 4 : (env_config == SERL_ENV_SYMMETRIC ? 1 : 10);
+  return A + nx + (incremental ? A : 0);
+}
+
+static int build_obs(double *obs, int cfg, int incr, int A, const double *err, const double *x, const double *last_u)
+{
+  int n = 0;
+  for (int i = 0; i < A; ++i) obs[n++] = err[i];
+  if (cfg == SERL_ENV_ATTITUDE) { obs[n++] = x[0]; obs[n++] = x[1]; obs[n++] = x[2]; obs[n++] = x[4]; }
+  else if (cfg == SERL_ENV_SYMMETRIC) obs[n++] = x[1];
+  else for (int i = 0; i < 10; ++i) obs[n++] = x[i];
+  if (incr) for (int i = 0; i < A; ++i) obs[n++] = last_u[i];
+  return n;
+}
+
 static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, int e, CitInstance *I, float *hbuf)
 {
   const double PI = 3.14159265358979323846;
   const double deg2rad = PI / 180.0, rad2deg = 180.0 / PI;
-  const double bound = 10.0 * deg2rad;                 /* phlabenv.py:208 */
+  const int cfg = d->env_config, incr = d->incremental != 0;
+  const int A = serl_env_action_dim(cfg), S = serl_env_state_dim(cfg, incr);
+  if (S == 0 || S != d->state_dim || A != d->action_dim) return SERL_E_INVALID;
+  const double bound = (incr ? 25.0 : 10.0) * deg2rad; /* phlabenv.py:205-208: rate bound [rad/s] / deflection bound [rad] */
   const double low = -bound, high = bound;
   const double max_theta = 60.0 * deg2rad, max_phi = 75.0 * deg2rad;   /* :211-212 */
-  const double scaler[3] = {6.0 / PI * 1.0, 6.0 / PI * 1.0, 6.0 / PI * 4.0};  /* :231 */
+  const double scaler[3] = {6.0 / PI * 1.0, 6.0 / PI * 1.0, 6.0 / PI * 4.0};  /* :226-232 (one action: [1] * 6/pi) */
   const double dt = 0.01;                              /* phlabenv.py:81 (class attribute) */
   const serl_fault_row nominal = {1.0, INFINITY, INFINITY, 0.0, 0.0, 0, 0, 0};
   const serl_fault_row *f = d->faults ? &d->faults[e] : &nominal;
@@ -223,8 +247,10 @@ static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, in
     const int nr = d->noise_row ? d->noise_row[e] : e;
     if (nr >= 0) noise = d->action_noise + (size_t)nr * d->max_steps * 3;
   }
-  double cmd[10], x[12], err[3] = {0, 0, 0}, obs[7];
-  float obsf[7], a[3];
+  double cmd[10], x[12], err[3] = {0, 0, 0}, obs[16], nobs[16];
+  double u[3] = {0, 0, 0};                             /* env.last_u (phlabenv.py:412); incremental control integrates it */
+  float obsf[16], a[3] = {0, 0, 0};
+  const int TW = 2 * S + A + 3;                        /* floats per stored transition */
 
   /* reset (phlabenv.py:401-428) */
   cit_reset(I, bd->code, bd->ro, bd->t3, bd->x0, bd->dw0, bd->dt);
@@ -237,30 +263,31 @@ static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, in
   if (snoise) add_sensor_noise(x, snoise);             /* envs/noise/citation.py:71-82 on the value step() returns */
   const double V0 = x[3];
   double t = 0.0;
-  if (d->err0) for (int i = 0; i < 3; ++i) err[i] = d->err0[(size_t)e * 3 + i];
-  obs[0] = err[0]; obs[1] = err[1]; obs[2] = err[2];
-  obs[3] = x[0]; obs[4] = x[1]; obs[5] = x[2]; obs[6] = x[4];
+  if (d->err0) for (int i = 0; i < A; ++i) err[i] = d->err0[(size_t)e * 3 + i];
+  build_obs(obs, cfg, incr, A, err, x, u);
 
   double fitness = 0.0;
   int k = 0, cost_steps = 0, done = 0;
   while (!done) {
     if (k >= d->max_steps) return SERL_E_INVALID;     /* reference table too short */
-    for (int i = 0; i < 7; ++i) obsf[i] = (float)obs[i];
+    for (int i = 0; i < S; ++i) obsf[i] = (float)obs[i];
     actor_forward(d, w, obsf, a, hbuf);
-    double u[3];
+    double sc[3] = {0, 0, 0};
     if (noise) {
       /* agent.py:90-93: f32 action + f64 noise -> f64, clipped; scale_action then runs in f64 */
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < A; ++i) {
         double an = clipd((double)a[i] + noise[(size_t)k * 3 + i], -1.0, 1.0);
-        u[i] = low + 0.5 * (an + 1.0) * (high - low);
+        sc[i] = low + 0.5 * (an + 1.0) * (high - low);
         a[i] = (float)an;                              /* agent.py:93,103: the transition holds the executed action */
       }
     } else {
-      for (int i = 0; i < 3; ++i) {
+      for (int i = 0; i < A; ++i) {
         float s = 0.5f * (a[i] + 1.0f);               /* phlabenv.py:72-73, f32 part */
-        u[i] = low + (double)s * (high - low);
+        sc[i] = low + (double)s * (high - low);
       }
     }
+    /* phlabenv.py:377-380,446-450: incremental control integrates the commanded rate */
+    for (int i = 0; i < A; ++i) u[i] = incr ? u[i] + sc[i] * dt : sc[i];
     memset(cmd, 0, sizeof(cmd));
     cmd[0] = clipd(u[0] * f->elev_gain, -f->elev_clip, f->elev_clip);
     cmd[1] = clipd(u[1], -f->ail_clip, f->ail_clip);
@@ -271,13 +298,14 @@ static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, in
     double rk[3];
     if (rspec) ref_generate(rspec, t, d->t_max, rk);
     else { rk[0] = ref[(size_t)k * 3]; rk[1] = ref[(size_t)k * 3 + 1]; rk[2] = ref[(size_t)k * 3 + 2]; }
-    err[0] = rk[0] - x[7]; err[1] = rk[1] - x[6]; err[2] = rk[2] - x[5];
+    const double ctrl[3] = {x[7], x[6], x[5]};         /* :347-350 theta, phi, beta */
+    for (int i = 0; i < A; ++i) err[i] = rk[i] - ctrl[i];
     double rsum = 0.0;
-    for (int i = 0; i < 3; ++i) rsum = rsum + fabs(clipd(scaler[i] * err[i], -1.0, 1.0));
-    double reward = -rsum / 3.0;
+    for (int i = 0; i < A; ++i) rsum = rsum + fabs(clipd(scaler[i] * err[i], -1.0, 1.0));
+    double reward = -rsum / (double)A;
     /* cost (phlabenv.py:369-375; degrees compared with 0.75*max_phi in radians -- reference quirk) */
     int cost = (rad2deg * fabs(x[4]) > 11.0) || (rad2deg * fabs(x[6]) > 0.75 * max_phi) || (x[3] < V0 / 3.0);
-    double nobs[7] = {err[0], err[1], err[2], x[0], x[1], x[2], x[4]};
+    build_obs(nobs, cfg, incr, A, err, x, u);
     /* bounds (phlabenv.py:391-399) */
     done = (t >= d->t_max) || (fabs(x[7]) > max_theta) || (fabs(x[6]) > max_phi) || (x[9] < 50.0);
     if (done) reward += -1.0 / dt * (d->t_max - t) * 2.0;
@@ -286,11 +314,11 @@ static int run_episode(const serl_rollout_desc *d, const serl_build_desc *bd, in
     if (d->states) for (int i = 0; i < 12; ++i) d->states[((size_t)e * d->max_steps + k) * 12 + i] = x[i];
     if (d->rewards) d->rewards[(size_t)e * d->max_steps + k] = reward;
     if (d->transitions) {
-      float *tr = d->transitions + ((size_t)e * d->max_steps + k) * 20;
-      for (int i = 0; i < 7; ++i) tr[i] = (float)obs[i];
-      for (int i = 0; i < 3; ++i) tr[7 + i] = a[i];
-      for (int i = 0; i < 7; ++i) tr[10 + i] = (float)nobs[i];
-      tr[17] = (float)reward; tr[18] = done ? 1.0f : 0.0f; tr[19] = cost ? 1.0f : 0.0f;
+      float *tr = d->transitions + ((size_t)e * d->max_steps + k) * TW;
+      for (int i = 0; i < S; ++i) tr[i] = (float)obs[i];
+      for (int i = 0; i < A; ++i) tr[S + i] = a[i];
+      for (int i = 0; i < S; ++i) tr[S + A + i] = (float)nobs[i];
+      tr[2 * S + A] = (float)reward; tr[2 * S + A + 1] = done ? 1.0f : 0.0f; tr[2 * S + A + 2] = cost ? 1.0f : 0.0f;
     }
     fitness += reward;
     cost_steps += cost;

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('SERL_LIB') or os.path.join(os.path.dirname(os.path.ab
 EXPORTS = ['serl_abi_version', 'serl_last_error', 'serl_param_count', 'serl_ctx_create', 'serl_ctx_destroy',
            'serl_ctx_load_build', 'serl_rollout', 'serl_dyn_open_loop', 'serl_debug_profile', 'serl_last_rollout_ms', 'serl_ga_clone', 'serl_ga_crossover',
            'serl_ga_mutate', 'serl_ga_scaled_perturb', 'serl_ctx_refresh_env', 'serl_ga_sensitivity', 'serl_ga_novelty',
-           'serl_replay_scatter']
+           'serl_replay_scatter', 'serl_env_state_dim', 'serl_env_action_dim']
 
 
 class BuildDesc(ctypes.Structure):
@@ -30,7 +30,8 @@ class RolloutDesc(ctypes.Structure):
                 ('concurrent_episodes', ctypes.c_int32), ('pad_', ctypes.c_int32),
                 ('fitness', VP), ('length_steps', VP), ('length_t', VP), ('cost_steps', VP),
                 ('actions', VP), ('states', VP), ('rewards', VP), ('transitions', VP),
-                ('ref_spec', VP), ('ref_spec_stride', ctypes.c_int64)]
+                ('ref_spec', VP), ('ref_spec_stride', ctypes.c_int64),
+                ('env_config', ctypes.c_int32), ('incremental', ctypes.c_int32)]
 
 
 _lib = None
@@ -71,7 +72,7 @@ def lib():
     for f in EXPORTS:
         if f not in ('serl_last_error',):
             getattr(L, f).restype = ctypes.c_int
-    if L.serl_abi_version() != 4:
+    if L.serl_abi_version() != 5:
         raise RuntimeError('serl_amd: ABI version mismatch')
     _lib = L
     return L

@@ -46,16 +46,42 @@ def mode_key(mode):
     if m.lower().startswith('phlab_'):
         toks = m.lower().split('_')
         m = toks[2] if len(toks) == 3 else ''
-    if 'incremental' in m.lower():
-        # envs/phlabenv.py:174-176,377-380: incremental control integrates the action (last_u + a*dt) and widens the
-        # observation; the kernel implements the attitude configuration with direct deflection commands only
-        raise NotImplementedError('PH-LAB incremental-control modes (%r) are not supported by the GPU evaluator' % mode)
+    if 'incremental' in m.lower():          # envs/phlabenv.py:99: the nominal build (rate control: env_config below)
+        return 'nominal'
     if m == 'nominal' or 'h2000-v90' in m.lower():
         return 'nominal'
     m = m.lower()
     if m not in MODES and 'test' in m:
         return 'test'
     return m
+
+
+ENV_ATTITUDE, ENV_SYMMETRIC, ENV_FULL = 0, 1, 2       # serl_rollout_desc.env_config (include/serl_amd.h)
+
+
+def env_config(name):
+    """(env_config, incremental) of an env name `PHlab_<configuration>_<mode>` (envs/config.py:16-25) the way
+    CitationEnv reads it (envs/phlabenv.py:86-97: 'symmetric' / 'attitude' as substrings of the configuration, anything
+    else = full state; :175: 'incremental' as a substring of the mode).  A bare mode ('nominal', 'be', 'incremental' ...)
+    means the attitude configuration."""
+    n = name.lower()
+    cfg, mode = 'attitude', n
+    if n.startswith('phlab_') or n.startswith('ph'):
+        toks = n.split('_')
+        if len(toks) == 3:
+            cfg, mode = toks[1], toks[2]
+        else:
+            cfg, mode = toks[-1], ''
+    c = ENV_SYMMETRIC if 'symmetric' in cfg else (ENV_ATTITUDE if 'attitude' in cfg else ENV_FULL)
+    return c, 'incremental' in mode
+
+
+def env_dims(config, incremental=False):
+    """(state_dim, action_dim) of a configuration: observation = [error (A), observed states, last_u (A, incremental)]
+    (envs/phlabenv.py:213-220)"""
+    A = 1 if config == ENV_SYMMETRIC else 3
+    nx = {ENV_ATTITUDE: 4, ENV_SYMMETRIC: 1, ENV_FULL: 10}[config]
+    return A + nx + (A if incremental else 0), A
 
 
 def has_sensor_noise(mode):

@@ -196,6 +196,17 @@ static __device__ __forceinline__ float serl_dot7(float bias, const float (&w)[7
   return bias + ((p0 + p1) + (p2 + p3));
 }
 
+// first layer of an actor whose observation has S <= 16 entries (env configurations other than the attitude task): the same
+// four interleaved partial sums over ascending j
+static __device__ __forceinline__ float serl_dot_obs(float bias, const float (&w)[16], const float *obs, int S)
+{
+  float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (j < S) p[j & 3] = __builtin_fmaf(w[j], obs[j], p[j & 3]);
+  return bias + ((p[0] + p[1]) + (p[2] + p[3]));
+}
+
 template <int N>
 static __device__ __forceinline__ float serl_mac4_lanes(float bias, const float (&row)[N], float h)
 {
@@ -296,22 +307,25 @@ static __device__ __forceinline__ float serl_tree_sum_rt(float v0, float v1, int
 // The network is walked as one sequence of 32-column weight chunks (hidden layers, then the output layer); the
 // loads of chunk i+1 are issued before the multiply-adds of chunk i, so the L2/HBM latency of the weight rows
 // (the wavefront is alone on its SIMD: nothing else hides it) overlaps with arithmetic.
-template <class Sync>
+// X: the observation / action widths come from the descriptor (S <= 16 inputs, A <= 3 outputs; obs holds 16 floats) instead
+// of the attitude task's 7 / 3.
+template <bool X = false, class Sync>
 static __device__ void serl_actor_forward_wave(const serl_rollout_desc &dd, const float *w_generic,
-                                               const float obs[7], float act_out[3], Sync &sync)
+                                               const float *obs, float act_out[3], Sync &sync)
 {
+  const int S = X ? __builtin_amdgcn_readfirstlane(dd.state_dim) : 7, A = X ? __builtin_amdgcn_readfirstlane(dd.action_dim) : 3;
   // network shape is wave-uniform: pin it to SGPRs so that shape tests are scalar branches, not exec masks
   const int H = __builtin_amdgcn_readfirstlane(dd.hidden), L = __builtin_amdgcn_readfirstlane(dd.num_layers);
   const int act = __builtin_amdgcn_readfirstlane(dd.activation);
   serl_gptr w = (serl_gptr)w_generic;
   const int lane = threadIdx.x & 63;
   const int i0 = lane < H ? lane : H - 1, i1 = lane + 64 < H ? lane + 64 : H - 1;   // clamped row ids
-  const int io = lane < 3 ? lane : 2;                                                // output-layer row
+  const int io = lane < A ? lane : A - 1;                                            // output-layer row
   const bool two = H > 64;
   const int Ha = H < 64 ? H : 64, Hb = H - Ha;
   const int nch = (H + 31) >> 5;                       // chunks per row
   const size_t lstride = (size_t)H * H + 3 * (size_t)H;
-  serl_gptr hid = w + (size_t)H * 7 + H;               // first hidden layer
+  serl_gptr hid = w + (size_t)H * S + H;               // first hidden layer
   serl_gptr outl = hid + (size_t)L * lstride;          // output layer: Wo[3][H] bo[3]
   const int nchunks = (L + 1) * nch;
   float na[32], nb[32];                                // chunk in flight
@@ -331,12 +345,19 @@ static __device__ void serl_actor_forward_wave(const serl_rollout_desc &dd, cons
       }                                                                                            \
     } else {                                                                                       \
       serl_load_chunk(na, outl + (size_t)io * H, jc_, H);                                          \
-      if (jc_ == 0) nbi0 = (outl + (size_t)3 * H)[io];                                             \
+      if (jc_ == 0) nbi0 = (outl + (size_t)A * H)[io];                                             \
     }                                                                                              \
   } while (0)
   SERL_ISSUE(0);
   float h0a, h0b = 0.0f;
-  {
+  if constexpr (X) {
+    serl_gptr W = w, b = w + (size_t)H * S;
+    float wa[16], wb[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { wa[j] = j < S ? W[i0 * S + j] : 0.0f; wb[j] = (two && j < S) ? W[i1 * S + j] : 0.0f; }
+    h0a = serl_act(serl_dot_obs(b[i0], wa, obs, S), act);
+    if (two) h0b = serl_act(serl_dot_obs(b[i1], wb, obs, S), act);
+  } else {
     serl_gptr W = w, b = w + (size_t)H * 7;
     float wa[7], wb[7];
 #pragma unroll

@@ -20,6 +20,7 @@ void serl_launch_dyn_nominal(const RolloutArgs &a, const double *cmds, double *s
 void serl_launch_dyn_ice(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
 #define SERL_DECL_WAVE(v)                                                                                     \
   void serl_launch_rollout_wave_##v(const RolloutArgs &a, int grid, hipStream_t stream);                          \
+  void serl_launch_rollout_wavex_##v(const RolloutArgs &a, int grid, hipStream_t stream);                         \
   void serl_launch_dyn_wave_##v(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
 SERL_DECL_WAVE(nominal) SERL_DECL_WAVE(ice) SERL_DECL_WAVE(cg_timed) SERL_DECL_WAVE(gust) SERL_DECL_WAVE(test)
 
@@ -144,6 +145,18 @@ static void serl_launch_rollout_wave(int code, const RolloutArgs &a, int grid, h
   }
 }
 
+// env configurations other than the attitude task (serl_rollout_desc.env_config / incremental)
+static void serl_launch_rollout_wavex(int code, const RolloutArgs &a, int grid, hipStream_t stream)
+{
+  switch (code) {
+    case SERL_DYN_NOMINAL: serl_launch_rollout_wavex_nominal(a, grid, stream); break;
+    case SERL_DYN_ICE: serl_launch_rollout_wavex_ice(a, grid, stream); break;
+    case SERL_DYN_CG_TIMED: serl_launch_rollout_wavex_cg_timed(a, grid, stream); break;
+    case SERL_DYN_GUST: serl_launch_rollout_wavex_gust(a, grid, stream); break;
+    default: serl_launch_rollout_wavex_test(a, grid, stream); break;
+  }
+}
+
 static void serl_launch_dyn_wave(int code, const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream)
 {
   switch (code) {
@@ -195,6 +208,16 @@ int serl_ctx_refresh_env(serl_ctx *c)
 }
 
 int serl_abi_version(void) { return SERL_ABI_VERSION; }
+
+// envs/phlabenv.py:84-97 (obs_idx per configuration), :213-220 (n_obs)
+int serl_env_action_dim(int env_config) { return env_config == SERL_ENV_SYMMETRIC ? 1 : 3; }
+int serl_env_state_dim(int env_config, int incremental)
+{
+  if (env_config < 0 || env_config > 2) return 0;
+  const int A = serl_env_action_dim(env_config);
+  const int nx = env_config == SERL_ENV_ATTITUDE ? 4 : (env_config == SERL_ENV_SYMMETRIC ? 1 : 10);
+  return A + nx + (incremental ? A : 0);
+}
 const char *serl_last_error(void) { return g_err.c_str(); }
 
 int serl_ctx_create(int device, serl_ctx **out)
@@ -264,8 +287,13 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   if (d->n_episodes <= 0) return fail(SERL_E_INVALID, "serl_rollout: n_episodes <= 0");
   if (!d->weights || !d->member_of_episode || (!d->ref && !d->ref_spec) || !d->fitness || !d->length_steps || !d->length_t || !d->cost_steps)
     return fail(SERL_E_INVALID, "serl_rollout: required device pointer is NULL");
-  if (d->state_dim != 7 || d->action_dim != 3)
-    return fail(SERL_E_UNSUPPORTED, "serl_rollout: only the PH-LAB attitude task (state_dim 7, action_dim 3) is compiled in");
+  const bool general_env = d->env_config != SERL_ENV_ATTITUDE || d->incremental != 0;
+  if (serl_env_state_dim(d->env_config, d->incremental) == 0)
+    return fail(SERL_E_INVALID, "serl_rollout: env_config must be SERL_ENV_ATTITUDE, SERL_ENV_SYMMETRIC or SERL_ENV_FULL");
+  if (d->state_dim != serl_env_state_dim(d->env_config, d->incremental) || d->action_dim != serl_env_action_dim(d->env_config))
+    return fail(SERL_E_INVALID, "serl_rollout: state_dim / action_dim do not match the env configuration (attitude 7 / 3, symmetric 2 / 1, full 13 / 3; incremental adds action_dim observations)");
+  if (general_env && d->lanes_per_wave > 0)
+    return fail(SERL_E_UNSUPPORTED, "serl_rollout: the lane-per-episode kernels exist for the attitude task only");
   if (d->hidden < 2 || d->hidden > SERL_MAX_HIDDEN || d->num_layers < 0 || d->num_layers > 16)
     return fail(SERL_E_UNSUPPORTED, "serl_rollout: hidden size / layer count out of range");
   if (d->hidden % 4 != 0 || d->weight_stride % 4 != 0 || ((uintptr_t)d->weights & 15) != 0)
@@ -294,6 +322,19 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   const bool timed = d->concurrent_episodes <= 0;
   const int together = d->n_episodes + (d->concurrent_episodes > 0 ? d->concurrent_episodes : 0);   // episodes sharing the GPU
   a.e0 = 0; a.e_end = d->n_episodes;
+  if (general_env) {
+    // observation set / number of actions / incremental control from the descriptor: one wavefront per episode, whatever the count
+    if (!serl_has_wave_kernel(s.code)) return fail(SERL_E_UNSUPPORTED, "serl_rollout: code variant without a wave kernel");
+    const int wpb = serl_wave_kernel_waves_per_block(c, together + (timed ? 0 : 16));
+    a.lanes = 1;
+    a.block = 64 * wpb;
+    if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
+    serl_launch_rollout_wavex(s.code, a, (d->n_episodes + wpb - 1) / wpb, stream);
+    HIP_TRY(hipGetLastError());
+    if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
+    c->timed = timed;
+    return SERL_OK;
+  }
   if (lanes <= 0 && serl_use_team(c, s.code, together)) {
     a.lanes = 1;
     a.block = 128;

@@ -111,9 +111,15 @@ class RolloutEngine:
     # ------------------------------------------------------------------------------------------
     def rollout(self, weights, spec: NetSpec, member_of_episode, ref, *, build='h2000_v90', faults=None,
                 err0=None, tick0=None, action_noise=None, noise_row=None, sensor_noise=None, sensor_row=None, t_max=80.0, traces=False,
-                transitions=False, lanes_per_wave=0, sync=True, concurrent_episodes=0):
+                transitions=False, lanes_per_wave=0, sync=True, concurrent_episodes=0, env_config=0, incremental=False):
         """Low-level: run len(member_of_episode) episodes.  weights f32 [M, >=P] (device or host),
-        ref f64 [E, T, 3] or [T, 3] radians.  Returns dict of device tensors."""
+        ref f64 [E, T, 3] or [T, 3] radians.  env_config / incremental: builds.env_config(name) (the attitude task by
+        default; the per-episode tables keep their 3-column layouts, transitions have 2 S + A + 3 columns).
+        Returns dict of device tensors."""
+        S_, A_ = builds.env_dims(env_config, incremental)
+        if (spec.state_dim, spec.action_dim) != (S_, A_):
+            raise ValueError('actor %d -> %d does not fit the env configuration (%d observations, %d actions)'
+                             % (spec.state_dim, spec.action_dim, S_, A_))
         dev = self.device
         w = torch.as_tensor(weights, dtype=torch.float32).to(dev)
         if w.shape[1] % 4 or w.stride(0) % 4 or not w.is_contiguous():
@@ -136,11 +142,11 @@ class RolloutEngine:
                    cost_steps=torch.zeros(E, dtype=torch.int32, device=dev))
         d = _capi.RolloutDesc(state_dim=spec.state_dim, action_dim=spec.action_dim, hidden=spec.hidden,
                               num_layers=spec.num_layers, activation=spec.activation_id, n_members=w.shape[0],
-                              weights=w.data_ptr(), weight_stride=w.stride(0), n_episodes=E,
+                              weights=w.data_ptr(), weight_stride=w.stride(0) if w.shape[0] > 1 else w.shape[1], n_episodes=E,   # (a [1, P] view may carry stride 0)
                               build_slot=self.slot_of(build), member_of_episode=moe.data_ptr(),
                               ref=0 if ref_t is None else ref_t.data_ptr(), ref_stride=0 if shared else T * 3, t_max=float(t_max),
                               max_steps=T, lanes_per_wave=int(lanes_per_wave),
-                              concurrent_episodes=int(concurrent_episodes),
+                              concurrent_episodes=int(concurrent_episodes), env_config=int(env_config), incremental=int(bool(incremental)),
                               fitness=out['fitness'].data_ptr(), length_steps=out['length_steps'].data_ptr(),
                               length_t=out['length_t'].data_ptr(), cost_steps=out['cost_steps'].data_ptr())
         keep = [w, moe, ref_t, spec_t]
@@ -182,7 +188,7 @@ class RolloutEngine:
                 out['rewards'] = torch.zeros(E, T, dtype=torch.float64, device=dev)
                 d.states, d.rewards = out['states'].data_ptr(), out['rewards'].data_ptr()
         if transitions:
-            out['transitions'] = torch.zeros(E, T, 20, dtype=torch.float32, device=dev)
+            out['transitions'] = torch.zeros(E, T, 2 * spec.state_dim + spec.action_dim + 3, dtype=torch.float32, device=dev)
             d.transitions = out['transitions'].data_ptr()
         stream = torch.cuda.current_stream(dev).cuda_stream
         _capi.check(self.lib.serl_rollout(self.ctx, ctypes.byref(d), ctypes.c_void_p(stream)), 'serl_rollout')
@@ -240,7 +246,9 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
 
     actors : sequence of Actor / GeneticAgent, or a packed f32 tensor [pop, P] (then pass `spec`)
     mode   : PH-LAB mode or env name ('nominal', 'be', 'PHlab_attitude_ice', ...; envs/phlabenv.py:99-172);
-             a sequence gives one mode per episode (mixed-fault sweeps: one kernel launch per dynamics build)
+             a sequence gives one mode per episode (mixed-fault sweeps: one kernel launch per dynamics build).
+             Env names select the configuration too ('PHlab_symmetric_nominal', 'PHlab_full_incremental', ...:
+             builds.env_config; one configuration per call, the actors must have its state_dim / action_dim)
     refs   : f64 [pop*num_evals, T, 3] / [num_evals, T, 3] / [T, 3] radians tables (refsignals.tabulate), or
              refsignals.ref_specs rows [pop*num_evals] / [num_evals] / [1] (generated inside the kernel: no table in HBM);
              None = the fixed base evaluation reference for every episode (the reference's training loop draws a new
@@ -274,6 +282,10 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
     modes = [mode] * E if isinstance(mode, str) else list(mode)
     assert len(modes) == E
     resolved = [builds.resolve_mode(m) for m in modes]
+    envs = {builds.env_config(m) for m in modes}
+    if len(envs) != 1:
+        raise ValueError('one env configuration per evaluate_pop call (got %s)' % sorted(envs))
+    env_cfg, incremental = envs.pop()
     need_actions = traces or smooth_fitness or need_smoothness
     want = True if traces else ('actions' if need_actions else False)
     tick0 = None if tick0 is None else np.asarray(tick0, dtype=np.int32).reshape(E)
@@ -314,7 +326,7 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
                                faults=faults, err0=None if err0 is None else err0[idx],
                                tick0=None if tick0 is None else tick0[idx], t_max=t_max, sensor_noise=sn, sensor_row=sr,
                                traces=want, transitions=transitions, lanes_per_wave=lanes_per_wave, sync=not many,
-                               concurrent_episodes=(E - len(idx)) if many else 0)
+                               concurrent_episodes=(E - len(idx)) if many else 0, env_config=env_cfg, incremental=incremental)
         if whole:
             out = o
             kernel_ms = engine.last_kernel_ms

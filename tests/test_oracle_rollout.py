@@ -443,3 +443,42 @@ def test_elu_activation_spec_and_closed_loop_vs_reference(golden):
         np.testing.assert_allclose(o['fitness'][e], fit, rtol=RTOL)
         np.testing.assert_allclose(o['actions'][e][:int(n)], g['actions_%d' % g['actors'][e]], atol=5e-3)     # (a saturating, oscillating controller: f32 rounding of the actor shows at 3e-3 rad late in the episode; the return agrees to 1e-5)
     assert (g['ret'][:, 3] < 2001).sum() == 2
+
+
+CONFIG_CASES = ['sym', 'sym_soft', 'sym_inc_n', 'full', 'att_inc', 'att_inc_soft', 'full_inc_n', 'att_inc_n']
+
+
+def config_case(g, name):
+    """inputs of one case of config.npz (tests/golden/make_config_golden.py) in the layouts of serl_rollout_desc"""
+    cfg, incr, S, A, H, L = (int(v) for v in g[name + '_cfg'])
+    net = dict(state_dim=S, action_dim=A, hidden=H, num_layers=L, activation=str(g[name + '_act']))
+    rows = g[name + '_rows']
+    T = len(rows)
+    ref = np.zeros((T + 1, 3)); ref[:T, :A] = g[name + '_ref']
+    noise = np.zeros((1, T + 1, 3)); noise[0, :T, :A] = g[name + '_noise']
+    return cfg, incr, net, rows, ref, (noise if np.any(noise) else None)
+
+
+@pytest.mark.parametrize('name', CONFIG_CASES)
+def test_env_configurations_vs_reference_python(golden, name):
+    """symmetric / full observation sets and incremental (rate) control, envs/phlabenv.py:84-97,174-176,205-220,377-380:
+    every stored transition of the reference's own Agent.evaluate (obs S, action A, next_obs S, reward, done), every cost
+    flag, env.last_u of every step, return and length -- random actors built by the reference's own Actor class."""
+    from oracle import rollout as R
+    g = golden('config')
+    cfg, incr, net, rows, ref, noise = config_case(g, name)
+    S, A, T = net['state_dim'], net['action_dim'], len(rows)
+    o = R.rollout(g[name + '_w'][None], net, [0], ref, t_max=20, action_noise=noise, traces=True, transitions=True,
+                  env_config=cfg, incremental=incr)
+    ret = g[name + '_ret']
+    assert int(o['length_steps'][0]) == T == int(ret[2])
+    assert o['length_t'][0] == ret[1]
+    np.testing.assert_allclose(o['fitness'][0], ret[0], rtol=RTOL)
+    tr = o['transitions'][0, :T].astype(np.float64)
+    assert tr.shape[1] == 2 * S + A + 3
+    # the f32 rows against the reference's f64 tuples: what the learners build FloatTensors from
+    np.testing.assert_allclose(tr[:, :2 * S + A + 2], rows, rtol=2e-4, atol=2e-5)
+    np.testing.assert_array_equal(tr[:, 2 * S + A + 1], rows[:, -1])                        # done flags
+    np.testing.assert_array_equal(tr[:, 2 * S + A + 2].astype(np.int8), g[name + '_cost'])  # info['cost'] of every step
+    np.testing.assert_allclose(o['actions'][0, :T, :A], g[name + '_u'], rtol=1e-5, atol=1e-7)
+    assert not o['actions'][0, :T, A:].any()
