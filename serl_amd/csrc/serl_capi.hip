@@ -27,6 +27,7 @@ SERL_DECL_WAVE(nominal) SERL_DECL_WAVE(ice) SERL_DECL_WAVE(cg_timed) SERL_DECL_W
 // a team of wavefronts per episode (rollout_team.inc: 7 + the actor wavefront, two per SIMD): the latency-bound regime
 #define SERL_DECL_TEAM(v)                                                                                     \
   void serl_launch_rollout_team_##v(const RolloutArgs &a, int grid, hipStream_t stream);                          \
+  void serl_launch_rollout_teamx_##v(const RolloutArgs &a, int grid, hipStream_t stream);                         \
   void serl_launch_dyn_team_##v(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
 SERL_DECL_TEAM(nominal) SERL_DECL_TEAM(ice) SERL_DECL_TEAM(cg_timed) SERL_DECL_TEAM(gust) SERL_DECL_TEAM(test)
 
@@ -146,6 +147,17 @@ static void serl_launch_rollout_wave(int code, const RolloutArgs &a, int grid, h
 }
 
 // env configurations other than the attitude task (serl_rollout_desc.env_config / incremental)
+static void serl_launch_rollout_teamx(int code, const RolloutArgs &a, int grid, hipStream_t stream)
+{
+  switch (code) {
+    case SERL_DYN_NOMINAL: serl_launch_rollout_teamx_nominal(a, grid, stream); break;
+    case SERL_DYN_ICE: serl_launch_rollout_teamx_ice(a, grid, stream); break;
+    case SERL_DYN_CG_TIMED: serl_launch_rollout_teamx_cg_timed(a, grid, stream); break;
+    case SERL_DYN_GUST: serl_launch_rollout_teamx_gust(a, grid, stream); break;
+    default: serl_launch_rollout_teamx_test(a, grid, stream); break;
+  }
+}
+
 static void serl_launch_rollout_wavex(int code, const RolloutArgs &a, int grid, hipStream_t stream)
 {
   switch (code) {
@@ -323,14 +335,27 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   const int together = d->n_episodes + (d->concurrent_episodes > 0 ? d->concurrent_episodes : 0);   // episodes sharing the GPU
   a.e0 = 0; a.e_end = d->n_episodes;
   if (general_env) {
-    // observation set / number of actions / incremental control from the descriptor: one wavefront per episode, whatever the count
+    // observation set / number of actions / incremental control from the descriptor: the team kernel while the episodes fit two
+    // rounds of workgroups (2 x ~23 us per env step against 57 of one wavefront per episode), one wavefront per episode beyond
     if (!serl_has_wave_kernel(s.code)) return fail(SERL_E_UNSUPPORTED, "serl_rollout: code variant without a wave kernel");
-    const int wpb = serl_wave_kernel_waves_per_block(c, together + (timed ? 0 : 16));
-    a.lanes = 1;
-    a.block = 64 * wpb;
+    const bool team = c->env_team >= 0 ? c->env_team != 0 : (d->concurrent_episodes <= 0 ? together <= 2 * c->num_cus : together <= c->num_cus);
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
-    serl_launch_rollout_wavex(s.code, a, (d->n_episodes + wpb - 1) / wpb, stream);
-    HIP_TRY(hipGetLastError());
+    if (team) {
+      a.lanes = 1;
+      a.block = 512;
+      for (int e0 = 0; e0 < d->n_episodes; e0 += c->num_cus) {
+        const int n = d->n_episodes - e0 < c->num_cus ? d->n_episodes - e0 : c->num_cus;
+        a.e0 = e0; a.e_end = e0 + n;
+        serl_launch_rollout_teamx(s.code, a, n, stream);
+        HIP_TRY(hipGetLastError());
+      }
+    } else {
+      const int wpb = serl_wave_kernel_waves_per_block(c, together + (timed ? 0 : 16));
+      a.lanes = 1;
+      a.block = 64 * wpb;
+      serl_launch_rollout_wavex(s.code, a, (d->n_episodes + wpb - 1) / wpb, stream);
+      HIP_TRY(hipGetLastError());
+    }
     if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = timed;
     return SERL_OK;
