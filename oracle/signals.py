@@ -67,6 +67,8 @@ class RandomizedCosineStepSequence(SmoothedStepSequence):
         levels = np.linspace(-ampl_max, ampl_max, n_levels)
         times = np.arange(0.0, t_max, block_width)
         amps = rng.choice(levels, size=len(times))
+        if vary_timings:            # block starts jittered by +-vary_timings (same guess as serl_amd.refsignals.randomized_cosine_steps)
+            times = np.concatenate([times[:1], times[1:] + rng.uniform(-vary_timings, vary_timings, len(times) - 1)])
         super().__init__(times, amps, max(float(smooth_width), 1e-6))
 
 

@@ -111,21 +111,21 @@ def sensor_terms(z):
     return t
 
 
-def draw_episode_noise(n_steps, action, sensor, rng=np.random):
+def draw_episode_noise(n_steps, action, sensor, rng=np.random, n_actions=3):
     """The np.random draws of ONE sequential reference episode, pre-drawn in the reference's interleaved order:
-    reset() -> step(): sensor model 7 draws (if the mode has one); then per env step: exploration noise randn(3)
-    (base/core/agent.py:91, if enabled) followed by the sensor model's 7 draws inside env.step().
-    -> (z_action [n_steps, 3] standard normals or None, sensor table [n_steps + 1, 7] or None, resync)
+    reset() -> step(): sensor model 7 draws (if the mode has one); then per env step: exploration noise randn(n_actions)
+    (base/core/agent.py:91 `randn(action.shape[0])`, if enabled) followed by the sensor model's 7 draws inside env.step().
+    -> (z_action [n_steps, n_actions] standard normals or None, sensor table [n_steps + 1, 7] or None, resync)
     where resync(n) rewinds the generator and re-draws exactly what an episode of n steps consumes, so that a seeded run
     leaves np.random where the reference's run leaves it (an episode that ends early draws less)."""
-    per = (3 if action else 0) + (7 if sensor else 0)
+    per = (n_actions if action else 0) + (7 if sensor else 0)
     head = 7 if sensor else 0
     if per == 0:
         return None, None, (lambda n: None)
     state = rng.get_state()
     z = rng.randn(head + n_steps * per)
     body = z[head:].reshape(n_steps, per)
-    za = body[:, :3].copy() if action else None
+    za = body[:, :n_actions].copy() if action else None
     sn = None
     if sensor:
         sn = sensor_terms(np.concatenate([z[:7][None], body[:, per - 7:]], 0))

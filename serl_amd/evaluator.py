@@ -455,6 +455,8 @@ def make_evaluate(args, *, mode='nominal', t_max=20, ref_fn=None, engine=None, r
     num_frames / gen_frames / num_episodes increments."""
     engine = engine or default_engine()
     counters = counters if counters is not None else {}
+    env_cfg, incremental = builds.env_config(mode)          # 'PHlab_symmetric_nominal', 'PHlab_full_incremental', ...
+    S, A = builds.env_dims(env_cfg, incremental)
     # envs/phlabenv.py never clears self.error between episodes, and the native initialize() never resets the model clock
     state = {'err': np.zeros(3), 'tick': 0}
 
@@ -463,9 +465,10 @@ def make_evaluate(args, *, mode='nominal', t_max=20, ref_fn=None, engine=None, r
         actor.eval()
         spec = spec_of(actor)
         if ref_fn is None:
-            th, ph = refsignals.training_references(1, t_max, np.random)
+            th, ph = refsignals.training_references(1, t_max, np.random, n_actions=A)
             theta0 = float(np.asarray(builds.load(builds.resolve_mode(mode)[0])[0]['x0'])[7])
-            ref = refsignals.tabulate(th[0], ph[0], t_max, theta_trim_deg=float(np.rad2deg(theta0)))
+            # (one action: init_ref keeps the class default 0.22 deg, envs/phlabenv.py:202,304-313)
+            ref = refsignals.tabulate(th[0], ph[0], t_max, theta_trim_deg=float(np.rad2deg(theta0)) if A == 3 else 0.22)
         elif isinstance(ref_fn, str) and ref_fn == 'base':
             ref = refsignals.tabulate(*refsignals.base_reference(t_max), t_max)
         else:
@@ -477,28 +480,33 @@ def make_evaluate(args, *, mode='nominal', t_max=20, ref_fn=None, engine=None, r
         T = ref_table.shape[0]
         # agent.py:90-93 / envs/noise/citation.py:71-82: this episode's np.random draws, pre-drawn in the reference's
         # interleaved per-step order; the generator is re-synchronised to the steps actually taken afterwards
-        za, sn, resync = builds.draw_episode_noise(T, bool(is_action_noise), builds.has_sensor_noise(mode), np.random)
-        noise = None if za is None else np.clip(args.noise_sd * za, -args.noise_clip, args.noise_clip)[None]
+        za, sn, resync = builds.draw_episode_noise(T, bool(is_action_noise), builds.has_sensor_noise(mode), np.random, n_actions=A)
+        noise = None
+        if za is not None:
+            noise = np.zeros((1, T, 3))
+            noise[0, :, :A] = np.clip(args.noise_sd * za, -args.noise_clip, args.noise_clip)
         build, row = builds.resolve_mode(mode)
         out = engine.rollout(pack_population([actor]), spec, [0], ref, build=build, sensor_noise=None if sn is None else sn[None],
                              faults=None if row == builds.NOMINAL_ROW else [row], err0=state['err'][None], tick0=[state['tick']],
-                             action_noise=noise, t_max=t_max, traces=True, transitions=store_transition)
+                             action_noise=noise, t_max=t_max, traces=True, transitions=store_transition,
+                             env_config=env_cfg, incremental=incremental)
         resync(abs(int(out['length_steps'][0])))
         n = int(out['length_steps'][0])
         state['tick'] += abs(n) + 1          # one step in reset() + n env steps
-        actions = out['actions'][0, :n].cpu().numpy()
+        actions = out['actions'][0, :n, :A].cpu().numpy()          # env.last_u per step (A columns)
         rewards = out['rewards'][0, :n].cpu().numpy()
         states = out['states'][0, :n].cpu().numpy()
-        state['err'] = ref_table[n - 1] - states[n - 1][[7, 6, 5]]
+        state['err'][:A] = (ref_table[n - 1] - states[n - 1][[7, 6, 5]])[:A]
         if store_transition:
             from . import replay
-            replay.store_episodes(engine, out['transitions'], [(agent, 0, n, int(out['cost_steps'][0]))], replay_buffer, counters)
+            replay.store_episodes(engine, out['transitions'], [(agent, 0, n, int(out['cost_steps'][0]))], replay_buffer, counters,
+                                  state_dim=S, action_dim=A)
         smooth = float(metrics.calc_smoothness(actions[None], [n])[0])
         fitness = float(np.sum(rewards))
         if getattr(args, 'smooth_fitness', False):
             fitness += smooth
         return Episode(fitness=fitness, smoothness=smooth, length=float(out['length_t'][0]),
-                       state_history=[] if store_transition else list(states), ref_signals=ref_table[n - 1],
+                       state_history=[] if store_transition else list(states), ref_signals=ref_table[n - 1][:A],
                        actions=actions, reward_lst=list(rewards))
 
     return evaluate

@@ -216,11 +216,17 @@ def randomized_cosine_steps(t_max, ampl_max, block_width, smooth_width, n_levels
     return SmoothedStepSequence(times, amps, max(float(smooth_width), 1e-6))
 
 
-def training_references(n_episodes, t_max=20, rng=np.random):
+def training_references(n_episodes, t_max=20, rng=np.random, n_actions=3):
     """What CitationEnv.reset() draws per training episode (envs/phlabenv.py:316-335): theta (+-30 deg) and phi (+-20 deg)
-    step sequences with block t_max//5, smooth t_max//6, t_max//2 levels, timing jitter t_max/500.  -> (thetas, phis)."""
+    step sequences with block t_max//5, smooth t_max//6, t_max//2 levels, timing jitter t_max/500.  -> (thetas, phis).
+    n_actions = 1 (the symmetric configuration, :304-313): one theta sequence with smooth t_max//6.7 and jitter t_max//500,
+    no phi draw (-> a zero sequence)."""
     th, ph = [], []
     for _ in range(n_episodes):
+        if n_actions == 1:
+            th.append(randomized_cosine_steps(t_max, 30, t_max // 5, t_max // 6.7, t_max // 2, t_max // 500, rng))
+            ph.append(SmoothedStepSequence(np.zeros(1), np.zeros(1), 1.0))
+            continue
         th.append(randomized_cosine_steps(t_max, 30, t_max // 5, t_max // 6, t_max // 2, t_max / 500., rng))
         ph.append(randomized_cosine_steps(t_max, 20, t_max // 5, t_max // 6, t_max // 2, t_max / 500., rng))
     return th, ph

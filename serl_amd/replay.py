@@ -146,7 +146,7 @@ def scatter_episodes(engine, staged, jobs):
                 'serl_replay_scatter')
 
 
-def store_episodes(engine, staged, items, replay_buffer=None, counters=None):
+def store_episodes(engine, staged, items, replay_buffer=None, counters=None, state_dim=7, action_dim=3):
     """The buffer side of Agent.evaluate for several stored episodes at once (agent.py:101-125).
 
     items : [(agent, episode index in `staged`, n_steps, n_cost_steps)] in the reference's order (member by member, then
@@ -154,7 +154,9 @@ def store_episodes(engine, staged, items, replay_buffer=None, counters=None):
             cost-flagged rows to agent.critical_buffer; num_frames / gen_frames advance by the steps, num_episodes by one
             per episode.  Buffers that are DeviceReplay rings are filled by ONE serl_replay_scatter launch; any other
             object with the reference's `add(*transition)` is fed tuple by tuple from a host copy (compatibility with
-            the reference's list-backed ReplayMemory)."""
+            the reference's list-backed ReplayMemory).  Rows are (obs S, action A, next_obs S, reward, done, cost); the
+            device rings hold the attitude task's 20-float rows (S = 7, A = 3) only."""
+    S, A = int(state_dim), int(action_dim)
     jobs, host = [], []
     for agent, e, n, nc in items:
         n, nc = int(n), int(nc)
@@ -163,6 +165,9 @@ def store_episodes(engine, staged, items, replay_buffer=None, counters=None):
             if ring is None:
                 continue
             if isinstance(ring, DeviceReplay):
+                if (S, A) != (7, 3):
+                    raise NotImplementedError('DeviceReplay rings hold the 20-float rows of the attitude task; use list-backed '
+                                              'buffers (ReplayMemory) for the other env configurations')
                 jobs.append((ring, e, n, cost_only, rows))
             else:
                 host.append((ring, e, n, cost_only))
@@ -177,6 +182,6 @@ def store_episodes(engine, staged, items, replay_buffer=None, counters=None):
         if e not in cache:
             cache[e] = staged[e, :n].cpu().numpy()
         for r in cache[e]:
-            if cost_only and not r[19]:
+            if cost_only and not r[2 * S + A + 2]:
                 continue
-            ring.add(r[0:7].astype(np.float64), r[7:10], r[10:17].astype(np.float64), float(r[17]), float(r[18]))
+            ring.add(r[0:S].astype(np.float64), r[S:S + A], r[S + A:2 * S + A].astype(np.float64), float(r[2 * S + A]), float(r[2 * S + A + 1]))

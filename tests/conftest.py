@@ -103,7 +103,7 @@ class OracleEngine:
 
     def rollout(self, weights, spec, member_of_episode, ref, *, build='h2000_v90', faults=None, err0=None, tick0=None,
                 action_noise=None, noise_row=None, sensor_noise=None, sensor_row=None, t_max=80.0, traces=False,
-                transitions=False, lanes_per_wave=0, sync=True, concurrent_episodes=0):
+                transitions=False, lanes_per_wave=0, sync=True, concurrent_episodes=0, env_config=0, incremental=False):
         import numpy as np, torch
         from oracle import rollout as R
         net = dict(state_dim=spec.state_dim, action_dim=spec.action_dim, hidden=spec.hidden, num_layers=spec.num_layers,
@@ -111,7 +111,8 @@ class OracleEngine:
         w = np.asarray(torch.as_tensor(weights).cpu().numpy(), dtype=np.float32)
         o = R.rollout(w, net, np.asarray(member_of_episode), ref if isinstance(ref, np.ndarray) else np.asarray(ref), build=build,
                       faults=faults, err0=err0, tick0=tick0, action_noise=action_noise, noise_row=noise_row,
-                      sensor_noise=sensor_noise, sensor_row=sensor_row, t_max=t_max, traces=bool(traces), transitions=transitions)
+                      sensor_noise=sensor_noise, sensor_row=sensor_row, t_max=t_max, traces=bool(traces), transitions=transitions,
+                      env_config=env_config, incremental=incremental)
         return {k: torch.from_numpy(np.asarray(v)) for k, v in o.items()}
 
 

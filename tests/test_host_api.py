@@ -221,3 +221,45 @@ def test_make_evaluate_sequence_vs_reference_agent_evaluate(golden, oracle_engin
     """(host logic of make_evaluate on the CPU: the rollout itself is served by the oracle through tests/conftest.py's
     OracleEngine; the GPU suite runs the same sequences through the HIP kernel)"""
     run_sequence(golden, name, oracle_engine, mode)
+
+
+CONFIG_SEEDS = {'sym': 5101, 'sym_soft': 5111, 'sym_inc_n': 5102, 'full': 5103, 'att_inc': 5104, 'att_inc_soft': 5114,
+                'full_inc_n': 5105, 'att_inc_n': 5106}
+
+
+def run_config_episode(golden, name, engine):
+    """serl_amd.make_evaluate on an env NAME of another configuration ('PHlab_symmetric_incremental', ...) against the
+    reference's own Agent.evaluate in TRAINING mode (tests/golden/make_config_golden.py): the env draws its references itself
+    (refsignals.training_references; one theta sequence for the symmetric configuration), exploration noise is randn(A) per
+    step, the stored tuples are (obs S, action A, next_obs S, reward, done)."""
+    import types
+    import numpy as np, torch
+    import serl_amd
+    from serl_amd import actor as A
+    g = golden('config')
+    cfg, incr, S, Ad, H, L = (int(v) for v in g[name + '_cfg'])
+    args = types.SimpleNamespace(state_dim=S, action_dim=Ad, hidden_size=H, num_layers=L, activation_actor=str(g[name + '_act']),
+                                 smooth_fitness=False, noise_sd=0.2962183114680794, noise_clip=0.5)
+    mode = 'PHlab_%s_%s' % ({0: 'attitude', 1: 'symmetric', 2: 'full'}[cfg], 'incremental' if incr else 'nominal')
+    shared, counters = _ListBuf(), {}
+    evaluate = serl_amd.make_evaluate(args, mode=mode, t_max=20, engine=engine, replay_buffer=shared, counters=counters)
+    ag = serl_amd.GeneticAgent(args, buffer=_ListBuf(), critical_buffer=_ListBuf())
+    A.unpack_into(ag.actor, torch.from_numpy(g[name + '_w']))
+    np.random.seed(CONFIG_SEEDS[name])
+    ep = evaluate(ag, bool(np.any(g[name + '_noise'])), True)
+    fit, length, n, sm = g[name + '_ret']
+    assert len(ep.reward_lst) == int(n) and ep.length == length
+    np.testing.assert_allclose(ep.fitness, fit, rtol=1e-5)
+    if abs(sm) > 1e-6:
+        np.testing.assert_allclose(ep.smoothness, sm, rtol=2e-3)
+    assert ep.actions.shape == (int(n), Ad)
+    np.testing.assert_allclose(ep.actions, g[name + '_u'], rtol=1e-5, atol=1e-7)
+    assert counters == {'num_frames': int(n), 'gen_frames': int(n), 'num_episodes': 1}
+    assert len(shared) == len(ag.buffer) == int(n) and len(ag.critical_buffer) == int(g[name + '_cost'].sum())
+    rows = np.stack([np.concatenate([np.ravel(np.asarray(x, np.float64)) for x in t]) for t in shared])
+    np.testing.assert_allclose(rows, g[name + '_rows'], rtol=2e-4, atol=2e-5)
+
+
+@_pytest.mark.parametrize('name', sorted(CONFIG_SEEDS))
+def test_make_evaluate_other_env_configurations(golden, oracle_engine, name):
+    run_config_episode(golden, name, oracle_engine)
