@@ -255,6 +255,16 @@ typedef struct serl_replay_job {
 int serl_replay_scatter(serl_ctx *ctx, const float *staged, int64_t rows_per_episode, const serl_replay_job *jobs /* device */,
                         int32_t n_jobs, void *stream);
 
+/* calc_smoothness (base/core/utils.py:82-120) of n_episodes action traces of DIFFERENT lengths in one launch:
+ *   Y = fft(y, N) per channel, N = |lengths[e]|;  S = sum_c sum_{1 <= i < N/2} |Y_i,c|^2 * dt * f_i * 2 / N  with
+ *   f = linspace(dt, 1 / (2 dt), N/2 - 1);  out[e] = -sqrt(S) * 100 * (80 / (N dt))   (0 for N < 4)
+ * evaluated as a direct DFT (one thread per frequency, the N twiddles in LDS), so there is no per-length FFT plan.
+ * actions: f64 [n_episodes][episode_stride / 3][3] (env.last_u per step: serl_rollout_desc.actions), rows past N ignored;
+ * work: f64 [serl_smoothness_work_size(n_episodes, max_len)] scratch; max_len >= every |length|, <= 8192. */
+int serl_smoothness_work_size(int32_t n_episodes, int32_t max_len);
+int serl_smoothness(serl_ctx *ctx, const double *actions, int64_t episode_stride, const int32_t *lengths, int32_t n_episodes,
+                    int32_t max_len, double dt, double *work, double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,8 @@ LIB_PATH = os.environ.get('SERL_LIB') or os.path.join(os.path.dirname(os.path.ab
 EXPORTS = ['serl_abi_version', 'serl_last_error', 'serl_param_count', 'serl_ctx_create', 'serl_ctx_destroy',
            'serl_ctx_load_build', 'serl_rollout', 'serl_dyn_open_loop', 'serl_debug_profile', 'serl_last_rollout_ms', 'serl_ga_clone', 'serl_ga_crossover',
            'serl_ga_mutate', 'serl_ga_scaled_perturb', 'serl_ctx_refresh_env', 'serl_ga_sensitivity', 'serl_ga_novelty',
-           'serl_replay_scatter', 'serl_env_state_dim', 'serl_env_action_dim']
+           'serl_replay_scatter', 'serl_env_state_dim', 'serl_env_action_dim',
+           'serl_smoothness', 'serl_smoothness_work_size']
 
 
 class BuildDesc(ctypes.Structure):
@@ -69,6 +70,8 @@ def lib():
     L.serl_ga_sensitivity.argtypes = [VP, VP, ctypes.c_int64, i32, i32, i32, i32, i32, VP, i32, VP, i32, VP, VP]
     L.serl_ga_novelty.argtypes = [VP, VP, ctypes.c_int64, i32, i32, i32, i32, i32, VP, i32, VP, VP, i32, VP, VP]
     L.serl_replay_scatter.argtypes = [VP, VP, ctypes.c_int64, VP, i32, VP]
+    L.serl_smoothness.argtypes = [VP, VP, ctypes.c_int64, VP, i32, i32, ctypes.c_double, VP, VP, VP]
+    L.serl_smoothness_work_size.argtypes = [i32, i32]
     for f in EXPORTS:
         if f not in ('serl_last_error',):
             getattr(L, f).restype = ctypes.c_int

@@ -74,7 +74,8 @@ def evaluate_generation(pop: Sequence, rl_agent=None, *, args, mode='nominal', t
 
     pop      : GeneticAgent / Actor sequence (one network shape); rl_agent: the RL learner's agent or None
     args     : needs num_evals, smooth_fitness, noise_sd, noise_clip (base/parameters.py)
-    refs     : f64 [pop*num_evals (+1), T, 3] / [T, 3] radians (refsignals.tabulate); None = base reference
+    refs     : f64 [pop*num_evals (+1), T, 3] / [T, 3] radians (refsignals.tabulate), or refsignals.ref_specs rows
+               [pop*num_evals (+1)] / [1] (generated in the kernel); None = base reference
     rl_noise : f64 [T, 3] clipped exploration noise; None = drawn here as agent.py:90-93 would
     store    : append the transitions of every member's last evaluation and of the RL episode to the buffers"""
     engine = engine or default_engine()
@@ -97,10 +98,15 @@ def evaluate_generation(pop: Sequence, rl_agent=None, *, args, mode='nominal', t
     Etot = len(moe)
     if refs is None:
         refs = refsignals.tabulate(*refsignals.base_reference(t_max), t_max)
-    refs = torch.as_tensor(refs, dtype=torch.float64)
-    T = refs.shape[-2]
-    if refs.dim() == 3:
-        assert refs.shape[0] == Etot, 'one reference table per episode (pop*num_evals%s)' % (' + 1' if rl_agent is not None else '')
+    generated = isinstance(refs, np.ndarray) and refs.dtype.names is not None      # refsignals.ref_specs rows: generated in the kernel
+    if generated:
+        assert len(refs) in (1, Etot), 'one reference spec per episode (pop*num_evals%s)' % (' + 1' if rl_agent is not None else '')
+        T = refsignals.n_steps_for(t_max)
+    else:
+        refs = torch.as_tensor(refs, dtype=torch.float64)
+        T = refs.shape[-2]
+        if refs.dim() == 3:
+            assert refs.shape[0] == Etot, 'one reference table per episode (pop*num_evals%s)' % (' + 1' if rl_agent is not None else '')
     noise = None
     if rl_agent is not None:
         if rl_noise is None:
@@ -134,8 +140,11 @@ def evaluate_generation(pop: Sequence, rl_agent=None, *, args, mode='nominal', t
     rl_ep = None
     if rl_agent is not None:
         e = Etot - 1
-        ref_row = refs[e] if refs.dim() == 3 else refs
-        rl_ep = _episode(out, e, ref_row.cpu().numpy(), sm[e], smooth_fitness)
+        if generated:
+            ref_row = refsignals.tabulate_specs(refs[e:e + 1] if len(refs) > 1 else refs[:1], t_max)[0]
+        else:
+            ref_row = (refs[e] if refs.dim() == 3 else refs).cpu().numpy()
+        rl_ep = _episode(out, e, ref_row, sm[e], smooth_fitness)
         if store:
             stored.append((rl_agent, e, abs(int(ls[e])), int(cs[e])))
     if stored:

@@ -12,7 +12,15 @@ def calc_smoothness(actions, lengths=None, dt=0.01):
     E, T, A = actions.shape
     if lengths is None:
         lengths = torch.full((E,), T, dtype=torch.int64)
-    lengths = torch.as_tensor(lengths).to(torch.int64).cpu()
+    lengths = torch.as_tensor(lengths).to(torch.int64).cpu().abs()
+    # episodes of many different lengths (a training generation): an FFT library plans -- rocFFT compiles -- per length;
+    # the direct-DFT kernel (csrc/serl_metrics.hip) takes them all in one launch.  Full-length batches keep the FFT (one
+    # plan per table length, made once).
+    uniq = torch.unique(lengths)
+    if actions.is_cuda and A == 3 and T <= 8192 and not (len(uniq) == 1 and int(uniq[0]) == T):
+        out = _smoothness_dft(actions, lengths, dt)
+        if out is not None:
+            return out
     out = torch.empty(E, dtype=torch.float64, device=actions.device)
     for N in torch.unique(lengths).tolist():      # one batched FFT per distinct episode length
         idx = torch.nonzero(lengths == N).flatten().to(actions.device)
@@ -25,6 +33,25 @@ def calc_smoothness(actions, lengths=None, dt=0.01):
         freq = torch.linspace(dt, 1 / (2 * dt), N // 2 - 1, dtype=torch.float64, device=actions.device)
         rough = torch.einsum('eij,i->ej', Syy, freq) * 2 / N
         out[idx] = -(torch.sqrt(rough.sum(-1)) * 100 * (80 / (N * dt)))
+    return out
+
+
+def _smoothness_dft(actions, lengths, dt):
+    import ctypes
+    from . import _capi, evaluator
+    with torch.cuda.device(actions.device):
+        eng = evaluator.default_engine()
+    if eng.device != actions.device:
+        return None
+    L = _capi.lib()
+    a = actions.contiguous()
+    E, T, _ = a.shape
+    n = lengths.to(torch.int32).to(a.device)
+    work = torch.empty(int(L.serl_smoothness_work_size(E, T)), dtype=torch.float64, device=a.device)
+    out = torch.empty(E, dtype=torch.float64, device=a.device)
+    stream = torch.cuda.current_stream(a.device).cuda_stream
+    _capi.check(L.serl_smoothness(eng.ctx, a.data_ptr(), T * 3, n.data_ptr(), E, T, float(dt), work.data_ptr(), out.data_ptr(),
+                                  ctypes.c_void_p(stream)), 'serl_smoothness')
     return out
 
 

@@ -181,3 +181,32 @@ def test_default_config_epoch_runs_on_device(engine, golden):
         assert np.abs(out[slot] - w0[second]).max() > 1e-4 and np.abs(out[slot] - w0[first]).max() > 1e-4
     assert len(bufs[slot]) == min(2000, 2 * min(1000, len(bufs[first])))
     assert len(crits[slot]) == 0
+
+
+def test_smoothness_of_episodes_of_different_lengths(engine):
+    """serl_smoothness (direct DFT, one launch for any set of lengths) against the FFT formulation of calc_smoothness
+    (base/core/utils.py:82-120; metrics.calc_smoothness per distinct length) and against numpy's FFT on the host."""
+    import numpy as np, torch
+    from serl_amd import metrics
+    rng = np.random.default_rng(3)
+    lengths = np.array([1, 3, 4, 5, 6, 7, 64, 199, 200, 1001, 2001, 2001, 1503, 8001, 8000, 12], dtype=np.int64)
+    T = 8001
+    t = np.arange(T) * 0.01
+    y = np.zeros((len(lengths), T, 3))
+    for e in range(len(lengths)):
+        for c in range(3):
+            y[e, :, c] = 0.1 * np.sin(2 * np.pi * rng.uniform(0.1, 3.0) * t + rng.uniform(0, 6)) + 0.01 * rng.standard_normal(T)
+    a = torch.from_numpy(y).to(engine.device)
+    got = metrics.calc_smoothness(a, lengths).cpu().numpy()            # > 2 distinct lengths on the GPU: the DFT kernel
+    want = np.zeros(len(lengths))
+    for e, N in enumerate(lengths):
+        if N < 4:
+            continue
+        Y = np.fft.fft(y[e, :N], axis=0)[1:N // 2]
+        S = np.abs(Y * np.conj(Y)) * 0.01
+        f = np.linspace(0.01, 50.0, N // 2 - 1)
+        want[e] = -np.sqrt((S * f[:, None]).sum() * 2 / N) * 100 * (80 / (N * 0.01))
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
+    fft = torch.stack([metrics.calc_smoothness(a[e:e + 1, :int(lengths[e])], None)[0] for e in range(len(lengths))]).cpu().numpy()   # full-length batches: the FFT path
+    np.testing.assert_allclose(got, fft, rtol=1e-9, atol=1e-12)
+    assert got[0] == 0.0 and got[1] == 0.0                         # fewer than four steps: no spectrum (metrics.calc_smoothness)

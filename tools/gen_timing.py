@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Wall time of ONE training generation's evaluation stage as a SERL user would run it through the drop-in API
+(serl_amd.evaluate_generation + validate_actor: pop=50 x num_evals=3 GA episodes + the RL actor's exploration episode in one
+launch, the champion's and the RL actor's validation batches), against the kernel time inside it: what the host adds.
+    python tools/gen_timing.py [generations] [--profile]
+Prints one JSON line; the reference's Python needs ~1.2 s per 20 s episode per core (profiles/r02_reference_cpu.json)."""
+import sys, os, time, json, types, cProfile, pstats, io
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import serl_amd
+from serl_amd import refsignals, actor as A
+from serl_amd.replay import DeviceReplay
+
+G = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 5
+args = types.SimpleNamespace(state_dim=7, action_dim=3, hidden_size=32, num_layers=3, activation_actor='tanh', num_evals=3,
+                             smooth_fitness=True, noise_sd=0.2962183114680794, noise_clip=0.5)
+engine = serl_amd.RolloutEngine(0)
+w = np.load(os.path.join(os.path.dirname(__file__), '..', 'tests', 'golden', 'actors.npz'))['serl50']
+shared = DeviceReplay(800_000, engine.device, engine)
+mk = lambda: types.SimpleNamespace(buffer=DeviceReplay(8000, engine.device, engine), critical_buffer=DeviceReplay(8000, engine.device, engine))
+pop = []
+for m in range(50):
+    ag = mk(); ag.actor = serl_amd.Actor(args); A.unpack_into(ag.actor, torch.from_numpy(w[m])); pop.append(ag)
+rl = mk(); rl.actor = serl_amd.Actor(args); A.unpack_into(rl.actor, torch.from_numpy(w[7]))
+E = 50 * 3 + 1
+rng = np.random.RandomState(0)
+counters = {}
+
+
+def generation():
+    t = {}
+    t0 = time.perf_counter()
+    refs = refsignals.ref_specs(*refsignals.training_references(E, 20, rng), 0.2106)
+    t['refs'] = time.perf_counter() - t0; t0 = time.perf_counter()
+    g = serl_amd.evaluate_generation(pop, rl, args=args, t_max=20, refs=refs, engine=engine, replay_buffer=shared, counters=counters)
+    torch.cuda.synchronize()
+    t['evaluate_generation'] = time.perf_counter() - t0; t['kernel_generation'] = g.kernel_ms / 1e3; t0 = time.perf_counter()
+    champ = pop[g.pop.champion]
+    v1 = serl_amd.validate_actor(champ, tests=5, t_max=20, engine=engine)
+    t['validate_champion'] = time.perf_counter() - t0; t['kernel_validate'] = engine.last_kernel_ms / 1e3; t0 = time.perf_counter()
+    v2 = serl_amd.validate_actor(rl, tests=5, t_max=20, engine=engine)
+    torch.cuda.synchronize()
+    t['validate_rl'] = time.perf_counter() - t0
+    return t
+
+
+generation()      # warm-up (module loads, rocFFT plans)
+if '--profile' in sys.argv:
+    pr = cProfile.Profile(); pr.enable(); generation(); pr.disable()
+    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(35); print(s.getvalue()[:6000])
+ts = [generation() for _ in range(G)]
+mean = {k: float(np.mean([t[k] for t in ts])) * 1e3 for k in ts[0]}
+total = mean['refs'] + mean['evaluate_generation'] + mean['validate_champion'] + mean['validate_rl']
+steps = int(counters['num_frames'])
+print(json.dumps(dict(what='one generation: 151 + 5 + 5 episodes of 20 s (2 001 steps), drop-in API, ms', **{k: round(v, 2) for k, v in mean.items()},
+                      total_ms=round(total, 2), kernel_ms=round(mean['kernel_generation'] + 2 * mean['kernel_validate'], 2),
+                      stored_frames=steps)))
