@@ -44,14 +44,49 @@ def generation():
     return t
 
 
+class _Critic(torch.nn.Module):
+    """stand-in for TD3's twin critic (base/core/td3.py:17-85)"""
+
+    def __init__(self):
+        super().__init__()
+        self.q1 = torch.nn.Sequential(torch.nn.Linear(10, 32), torch.nn.ELU(), torch.nn.Linear(32, 1))
+        self.q2 = torch.nn.Sequential(torch.nn.Linear(10, 32), torch.nn.ELU(), torch.nn.Linear(32, 1))
+
+    def forward(self, s, a):
+        x = torch.cat([s, a], -1)
+        return self.q1(x), self.q2(x)
+
+
+def epoch(fitness):
+    """the reference's DEFAULT SSNE epoch (proximal mutation, distillation crossover, distance-sorted groups;
+    base/parameters.py:110-115) on the packed population with the generation's device rings"""
+    import random
+    from serl_amd import ssne
+    eargs = types.SimpleNamespace(pop_size=50, elite_fraction=0.2, mutation_prob=0.9, mutation_mag=0.0247682869654, mut_type='proximal',
+                                  distil_crossover=True, distil_type='distance', crossover_prob=0.0, mutation_batch_size=86,
+                                  individual_bs=8000)
+    t0 = time.perf_counter()
+    wts = serl_amd.pack_population([a.actor for a in pop], device=engine.device)
+    s = ssne.SSNE(eargs, engine, serl_amd.evaluator.spec_of(pop[0].actor), critic=critic)
+    s.epoch(wts, fitness, buffers=[a.buffer for a in pop], critical=[a.critical_buffer for a in pop])
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+critic = _Critic().to(engine.device)
 generation()      # warm-up (module loads, rocFFT plans)
 if '--profile' in sys.argv:
     pr = cProfile.Profile(); pr.enable(); generation(); pr.disable()
     s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(35); print(s.getvalue()[:6000])
 ts = [generation() for _ in range(G)]
+ep_ms = []
+if '--epoch' in sys.argv:
+    fit = np.random.default_rng(1).normal(-150, 50, 50)
+    epoch(fit)
+    ep_ms = [epoch(fit) * 1e3 for _ in range(3)]
 mean = {k: float(np.mean([t[k] for t in ts])) * 1e3 for k in ts[0]}
 total = mean['refs'] + mean['evaluate_generation'] + mean['validate_champion'] + mean['validate_rl']
 steps = int(counters['num_frames'])
 print(json.dumps(dict(what='one generation: 151 + 5 + 5 episodes of 20 s (2 001 steps), drop-in API, ms', **{k: round(v, 2) for k, v in mean.items()},
                       total_ms=round(total, 2), kernel_ms=round(mean['kernel_generation'] + 2 * mean['kernel_validate'], 2),
-                      stored_frames=steps)))
+                      stored_frames=steps, ssne_default_epoch_ms=[round(v, 1) for v in ep_ms])))
