@@ -265,6 +265,25 @@ int serl_smoothness_work_size(int32_t n_episodes, int32_t max_len);
 int serl_smoothness(serl_ctx *ctx, const double *actions, int64_t episode_stride, const int32_t *lengths, int32_t n_episodes,
                     int32_t max_len, double dt, double *work, double *out, void *stream);
 
+/* The training loop of SSNE.distilation_crossover (base/core/mod_neuro_evo.py:131-147) for all pairs of an epoch in one
+ * launch: n_steps[p] Adam steps (torch.optim.Adam defaults, lr) of GeneticAgent.update_parameters
+ * (base/core/genetic_agent.py:22-59) per pair, on minibatches slots[p][step][0 .. batch[p]) of the child's buffer:
+ *   loss = sum_kept (actor(state) - target)^2 + mean_kept(actor(state)^2)
+ * `targets` (the better parent's action per state) and `keep` (1 where the critic's Q-filter keeps the state) are what
+ * the parents and the critic contribute; they do not depend on the child and are computed once by the caller.
+ * child: f32 [n_pairs][stride], in = the second parent's parameters, out = the trained child.  states [n_pairs][rows][S],
+ * targets [n_pairs][rows][A], keep [n_pairs][rows], slots i32 [n_pairs][steps][128].  Compiled for hidden 32 x 3 layers
+ * (SERL_E_UNSUPPORTED otherwise). */
+int serl_ga_distill(serl_ctx *ctx, float *child, int64_t stride, int32_t n_pairs, int32_t state_dim, int32_t hidden, int32_t num_layers,
+                    int32_t action_dim, int32_t activation, const float *states, const float *targets, const float *keep, int32_t rows,
+                    const int32_t *slots, int32_t steps, const int32_t *n_steps, const int32_t *batch, float lr, void *stream);
+/* Host helper (no GPU work): the rows `random.sample(memory, k)` of base/core/replay_memory.py:72-73 picks from n
+ * transitions in `calls` consecutive calls, replayed from the generator's raw 32-bit outputs (CPython's set-based
+ * selection: n above its set-size threshold).  Returns the number of outputs consumed, -1 = n_words too small,
+ * -2 = n / k outside that branch.  out: i32 [calls][out_stride]. */
+long long serl_host_sample_slots(const uint32_t *words, long long n_words, int32_t n, int32_t k, int32_t calls, int32_t *out,
+                                 int32_t out_stride);
+
 #ifdef __cplusplus
 }
 #endif

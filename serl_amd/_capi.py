@@ -12,7 +12,7 @@ EXPORTS = ['serl_abi_version', 'serl_last_error', 'serl_param_count', 'serl_ctx_
            'serl_ctx_load_build', 'serl_rollout', 'serl_dyn_open_loop', 'serl_debug_profile', 'serl_last_rollout_ms', 'serl_ga_clone', 'serl_ga_crossover',
            'serl_ga_mutate', 'serl_ga_scaled_perturb', 'serl_ctx_refresh_env', 'serl_ga_sensitivity', 'serl_ga_novelty',
            'serl_replay_scatter', 'serl_env_state_dim', 'serl_env_action_dim',
-           'serl_smoothness', 'serl_smoothness_work_size']
+           'serl_smoothness', 'serl_smoothness_work_size', 'serl_ga_distill', 'serl_host_sample_slots']
 
 
 class BuildDesc(ctypes.Structure):
@@ -72,9 +72,11 @@ def lib():
     L.serl_replay_scatter.argtypes = [VP, VP, ctypes.c_int64, VP, i32, VP]
     L.serl_smoothness.argtypes = [VP, VP, ctypes.c_int64, VP, i32, i32, ctypes.c_double, VP, VP, VP]
     L.serl_smoothness_work_size.argtypes = [i32, i32]
+    L.serl_ga_distill.argtypes = [VP, VP, ctypes.c_int64, i32, i32, i32, i32, i32, i32, VP, VP, VP, i32, VP, i32, VP, VP, ctypes.c_float, VP]
+    L.serl_host_sample_slots.argtypes = [VP, ctypes.c_longlong, i32, i32, i32, VP, i32]
     for f in EXPORTS:
         if f not in ('serl_last_error',):
-            getattr(L, f).restype = ctypes.c_int
+            getattr(L, f).restype = ctypes.c_longlong if f == 'serl_host_sample_slots' else ctypes.c_int
     if L.serl_abi_version() != 5:
         raise RuntimeError('serl_amd: ABI version mismatch')
     _lib = L

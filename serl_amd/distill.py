@@ -72,3 +72,127 @@ def distilation_crossover(args, engine, spec, weights, first, second, buffers, c
             losses.append(update_parameters(child, optim, buf.sample(batch_size, rng), p1, p2, critic))
     row = pack_actor(child).to(dev)
     return row, buf, replay.DeviceReplay(cap, dev, engine)
+
+
+# ---- all distillations of an epoch in one launch ----------------------------------------------------------------------
+
+def sample_minibatches(n, k, calls, rng=random):
+    """`calls` consecutive `rng.sample(range(n), k)` -> int32 [calls, 128] (first k columns), consuming the generator exactly
+    like the python calls would.  The draws of a whole distillation (750 calls) cost ~50 ms of interpreter time one by one;
+    here the raw 32-bit outputs of the Mersenne Twister are taken in bulk (getrandbits) and CPython's selection algorithm
+    is replayed by a few lines of C (serl_host_sample_slots), after which the generator is rewound and advanced by the
+    number of outputs the python calls would have consumed."""
+    import ctypes
+    import numpy as np
+    from . import _capi
+    out = np.zeros((calls, 128), dtype=np.int32)
+    if calls == 0:
+        return out
+    fast = all(hasattr(rng, f) for f in ('getstate', 'setstate', 'getrandbits'))
+    if fast:
+        L = _capi.lib()
+        bits = int(n).bit_length()
+        m = int(calls * k * (2 ** bits / n) * 1.25) + 4096
+        state = rng.getstate()
+        while True:
+            words = np.frombuffer(rng.getrandbits(32 * m).to_bytes(4 * m, 'little'), dtype='<u4')
+            used = int(L.serl_host_sample_slots(words.ctypes.data, m, int(n), int(k), int(calls), out.ctypes.data, 128))
+            rng.setstate(state)
+            if used == -1:
+                m *= 2
+                continue
+            break
+        if used > 0:
+            rng.getrandbits(32 * used)
+            return out
+    for c in range(calls):                      # small buffers (CPython's pool-based branch) or a foreign generator
+        out[c, :k] = rng.sample(range(n), k)
+    return out
+
+
+def _batched_forward(spec, rows, states):
+    """Actor.forward for K actors at once: rows f32 [K, >=P] packed parameters, states f32 [K, n, S] -> actions [K, n, A]"""
+    from .actor import ACTIVATION_IDS
+    S, H, L, A = spec.state_dim, spec.hidden, spec.num_layers, spec.action_dim
+    act = {0: torch.tanh, 1: torch.nn.functional.elu, 2: lambda v: torch.nn.functional.leaky_relu(v, 0.01)}[ACTIVATION_IDS[spec.activation]]
+    K = rows.shape[0]
+    off = 0
+
+    def take(shape):
+        nonlocal off
+        n = 1
+        for d in shape:
+            n *= d
+        v = rows[:, off:off + n].reshape((K,) + shape)
+        off += n
+        return v
+    W, b = take((H, S)), take((H,))
+    h = act(torch.baddbmm(b[:, None, :], states, W.transpose(1, 2)))
+    for _ in range(L):
+        W, b, g, be = take((H, H)), take((H,)), take((H,)), take((H,))
+        y = torch.baddbmm(b[:, None, :], h, W.transpose(1, 2))
+        mean = y.mean(-1, keepdim=True)
+        std = y.std(-1, keepdim=True)
+        h = act(g[:, None, :] * (y - mean) / (std + 1e-6) + be[:, None, :])
+    W, b = take((A, H)), take((A,))
+    return torch.tanh(torch.baddbmm(b[:, None, :], h, W.transpose(1, 2)))
+
+
+def distil_batch(args, engine, spec, weights, pairs, buffers, critic, rng=random):
+    """All distillation crossovers of an epoch: pairs [(first, second)] in the reference's order ->
+    [(child row, child buffer, empty critical buffer)].  Host draws (buffer shuffle, the throw-away initialisation, the
+    minibatches) happen pair by pair in the reference's order; the parents' actions and the critic's Q-filter are evaluated
+    once per pair over the child's whole buffer; the 12 x (len // 128) Adam steps of all pairs run in ONE kernel launch
+    (serl_ga_distill).  Shapes the kernel is not compiled for train pair by pair in PyTorch (distilation_crossover)."""
+    import ctypes
+    import numpy as np
+    from . import _capi
+    if critic is None:
+        raise ValueError('distilation_crossover needs the learner\'s critic: SSNE(args, engine, spec, critic=...)')
+    dev = weights.device
+    fused = dev.type == 'cuda' and spec.hidden == 32 and spec.num_layers == 3 and spec.state_dim <= 16 and spec.action_dim <= 4
+    if not fused or not pairs:
+        return [distilation_crossover(args, engine, spec, weights, f, s, buffers, critic, rng) for f, s in pairs]
+    P, S, A = spec.param_count, spec.state_dim, spec.action_dim
+    cap = int(args.individual_bs)
+    bufs, slots, nsteps, batch = [], [], [], []
+    for first, second in pairs:
+        buf = replay.DeviceReplay(cap, dev, engine)
+        buf.add_latest_from(buffers[first], cap // 2)
+        buf.add_latest_from(buffers[second], cap // 2)
+        buf.shuffle(rng)
+        _actor_from_row(args, spec, weights[second, :P], 'cpu')          # GeneticAgent(args): the draws of its random initialisation
+        n = len(buf)
+        B = min(128, n)
+        iters = n // B if B else 0
+        bufs.append(buf)
+        slots.append(sample_minibatches(n, B, 12 * iters, rng))
+        nsteps.append(12 * iters)
+        batch.append(B)
+    K, rows, steps = len(pairs), max(len(b) for b in bufs), max(nsteps)
+    states = torch.zeros(K, max(rows, 1), S, dtype=torch.float32, device=dev)
+    for k, b in enumerate(bufs):
+        states[k, :len(b)] = b.rows[:len(b), :S]
+    with torch.no_grad():
+        a1 = _batched_forward(spec, weights[[f for f, _ in pairs]], states)
+        a2 = _batched_forward(spec, weights[[s for _, s in pairs]], states)
+        flat = states.reshape(-1, S)
+        q1 = torch.min(*critic(flat, a1.reshape(-1, A))).reshape(K, -1)
+        q2 = torch.min(*critic(flat, a2.reshape(-1, A))).reshape(K, -1)
+        eps = 10 ** -5
+        take1 = (q1 - q2) > eps                                           # genetic_agent.py:44-46
+        keep = (take1 | ((q2 - q1) >= eps)).to(torch.float32).contiguous()
+        targets = torch.where(take1[..., None], a1, a2).contiguous()
+    child = weights[[s for _, s in pairs]].clone().contiguous()           # hard_update(new_agent.actor, gene2.actor)
+    sl = np.zeros((K, max(steps, 1), 128), dtype=np.int32)
+    for k, s_ in enumerate(slots):
+        sl[k, :len(s_)] = s_
+    sl_t = torch.from_numpy(sl).to(dev)
+    ns_t = torch.tensor(nsteps, dtype=torch.int32, device=dev)
+    bt_t = torch.tensor(batch, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _capi.check(_capi.lib().serl_ga_distill(engine.ctx, child.data_ptr(), child.stride(0), K, S, spec.hidden, spec.num_layers, A,
+                                            spec.activation_id, states.data_ptr(), targets.data_ptr(), keep.data_ptr(), states.shape[1],
+                                            sl_t.data_ptr(), sl.shape[1], ns_t.data_ptr(), bt_t.data_ptr(), ctypes.c_float(1e-3),
+                                            ctypes.c_void_p(stream)), 'serl_ga_distill')
+    return [(child[k, :P], bufs[k], replay.DeviceReplay(cap, dev, engine)) for k in range(K)]

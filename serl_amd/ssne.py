@@ -164,6 +164,11 @@ class SSNE:
         from . import distill
         return distill.distilation_crossover(self.args, self.engine, self.spec, weights, int(first), int(second), buffers, self.critic)
 
+    def distilation_crossovers(self, weights, pairs, buffers):
+        """independent distillations [(first, second)] -> children, trained together (distill.distil_batch)"""
+        from . import distill
+        return distill.distil_batch(self.args, self.engine, self.spec, weights, pairs, buffers, self.critic)
+
     # ---- the generation update ------------------------------------------------------------------------------------
     def epoch(self, weights, fitness_evals, bcs_evals=None, buffers=None, critical=None):
         """weights: f32 [pop, stride] device tensor, edited in place; buffers / critical: per-member DeviceReplay lists
@@ -197,11 +202,18 @@ class SSNE:
                 groups = ga.sort_groups_by_distance(self.engine, weights, parents, buffers, self.spec, rng)
                 if bcs_evals is not None:                   # mod_neuro_evo.py:505 (see the module docstring)
                     groups = sort_groups_by_novelty(parents, np.asarray(bcs_evals))
+            # the children only replace unselected members, which are nobody's parents: the distillations of this loop do
+            # not depend on each other and train in one launch (distill.distil_batch); the host draws keep the reference's
+            # order (pair by pair: buffer shuffle, initialisation, minibatches), a clone draws nothing
+            pairs = []
             for k, unselected in enumerate(unselects):
                 first, second, _ = groups[k % len(groups)]
                 if fitness[first] < fitness[second]:
                     first, second = second, first
-                child = self.distilation_crossover(weights, first, second, buffers)
+                pairs.append((int(first), int(second)))
+            children = self.distilation_crossovers(weights, pairs, buffers)
+            for (first, second), unselected, child in zip(pairs, unselects, children):
+                self._rec(3, first, second)
                 self.clone(weights, -1, int(unselected), buffers, critical, master_rings=child)
         else:
             if len(unselects) % 2 != 0:

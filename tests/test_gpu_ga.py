@@ -210,3 +210,57 @@ def test_smoothness_of_episodes_of_different_lengths(engine):
     fft = torch.stack([metrics.calc_smoothness(a[e:e + 1, :int(lengths[e])], None)[0] for e in range(len(lengths))]).cpu().numpy()   # full-length batches: the FFT path
     np.testing.assert_allclose(got, fft, rtol=1e-9, atol=1e-12)
     assert got[0] == 0.0 and got[1] == 0.0                         # fewer than four steps: no spectrum (metrics.calc_smoothness)
+
+
+@pytest.mark.parametrize('name', ['d_18_0', 'd_7_33', 'd_0_18'])
+def test_fused_distillation_vs_reference(engine, golden, name):
+    """distill.distil_batch -- targets and Q-filter once per pair, all Adam steps in the serl_ga_distill kernel -- against the
+    child the REFERENCE'S OWN SSNE.distilation_crossover produced (tests/golden/make_distill_golden.py): same buffer, same
+    minibatches (the generator ends where the reference's ends), parameters to f32 rounding of 36 - 84 Adam steps."""
+    import random
+    from serl_amd import distill
+    from test_ga_host import distill_case
+    args, spec, w, bufs, critic, seed, g = distill_case(golden, name, engine.device, engine)
+    random.seed(seed); torch.manual_seed(seed)
+    (row, buf, crit), = distill.distil_batch(args, engine, spec, w, [(0, 1)], bufs, critic)
+    after = random.random()
+    np.testing.assert_array_equal(buf.rows[:len(buf), :7].cpu().numpy(), g[name + '_states'])
+    child = row.cpu().numpy()[:spec.param_count]
+    moved = np.abs(g[name + '_child'] - w[1].cpu().numpy()[:spec.param_count]).max()
+    assert moved > 5e-3
+    np.testing.assert_allclose(child, g[name + '_child'], rtol=0, atol=2e-4 * moved / 0.04 + 2e-5)
+    # the sequential PyTorch path from the same seed leaves python's generator at the same place
+    random.seed(seed); torch.manual_seed(seed)
+    row2, _, _ = distill.distilation_crossover(args, engine, spec, w, 0, 1, bufs, critic)
+    assert random.random() == after
+    np.testing.assert_allclose(child, row2.cpu().numpy()[:spec.param_count], rtol=0, atol=2e-4)
+
+
+def test_fused_distillation_of_several_pairs(engine, golden):
+    """four pairs with buffers of different fill in one launch == the same pairs trained one by one in PyTorch"""
+    import random
+    from serl_amd import distill, replay
+    from test_ga_host import distill_case
+    args, spec, w2, bufs2, critic, seed, g = distill_case(golden, 'd_18_0', engine.device, engine)
+    P, W = golden('proximal'), golden('actors')['serl50']
+    ids = [18, 0, 7, 33]
+    w = torch.from_numpy(W[ids]).to(engine.device)
+    bufs = []
+    for j, i in enumerate(ids):
+        r = replay.DeviceReplay(10_000, engine.device, engine)
+        r.append_rows(torch.from_numpy(P['buf_serl50_%d' % i][:1002 - 150 * j]))
+        bufs.append(r)
+    args.individual_bs = 1500
+    pairs = [(0, 1), (2, 3), (1, 2), (3, 0)]
+    random.seed(9); torch.manual_seed(9)
+    kids = distill.distil_batch(args, engine, spec, w, pairs, bufs, critic)
+    after = random.random()
+    random.seed(9); torch.manual_seed(9)
+    ref = [distill.distilation_crossover(args, engine, spec, w, f, s, bufs, critic) for f, s in pairs]
+    assert random.random() == after
+    for (row, buf, _), (row2, buf2, _), (f, s) in zip(kids, ref, pairs):
+        assert len(buf) == len(buf2) == min(750, len(bufs[f])) + min(750, len(bufs[s]))
+        np.testing.assert_array_equal(buf.rows[:len(buf)].cpu().numpy(), buf2.rows[:len(buf2)].cpu().numpy())
+        a, b = row.cpu().numpy()[:spec.param_count], row2.cpu().numpy()[:spec.param_count]
+        assert np.abs(a - w[s].cpu().numpy()[:spec.param_count]).max() > 5e-3
+        np.testing.assert_allclose(a, b, rtol=0, atol=3e-4)
