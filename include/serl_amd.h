@@ -277,10 +277,10 @@ int serl_smoothness(serl_ctx *ctx, const double *actions, int64_t episode_stride
 int serl_ga_distill(serl_ctx *ctx, float *child, int64_t stride, int32_t n_pairs, int32_t state_dim, int32_t hidden, int32_t num_layers,
                     int32_t action_dim, int32_t activation, const float *states, const float *targets, const float *keep, int32_t rows,
                     const int32_t *slots, int32_t steps, const int32_t *n_steps, const int32_t *batch, float lr, void *stream);
-/* Host helper (no GPU work): the rows `random.sample(memory, k)` of base/core/replay_memory.py:72-73 picks from n
- * transitions in `calls` consecutive calls, replayed from the generator's raw 32-bit outputs (CPython's set-based
- * selection: n above its set-size threshold).  Returns the number of outputs consumed, -1 = n_words too small,
- * -2 = n / k outside that branch.  out: i32 [calls][out_stride]. */
+/* Host helper (no GPU work): the rows `random.sample(memory, k)` of base/core/replay_memory.py:72-73,83-85 picks from n
+ * transitions in `calls` consecutive calls, replayed from the generator's raw 32-bit outputs (CPython's selection
+ * algorithm: set-based above its set-size threshold, pool-based below).  Returns the number of outputs consumed,
+ * -1 = n_words too small, -2 = bad arguments.  out: i32 [calls][out_stride], out_stride >= k. */
 long long serl_host_sample_slots(const uint32_t *words, long long n_words, int32_t n, int32_t k, int32_t calls, int32_t *out,
                                  int32_t out_stride);
 

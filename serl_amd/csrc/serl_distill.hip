@@ -288,28 +288,47 @@ __global__ void __launch_bounds__(DB) distill_kernel(DistillArgs a)
 
 extern "C" {
 
-// The minibatch rows `random.sample(memory, k)` picks from a list of n transitions (base/core/replay_memory.py:72-73), for
-// `calls` consecutive calls, from the raw 32-bit outputs of the generator: CPython's sample() -- for n above its set-size
-// threshold -- draws j = _randbelow(n) (getrandbits(n.bit_length()) = one 32-bit output shifted right, rejected while >= n)
-// and rejects a j it already holds.  words: the next outputs of the Mersenne Twister in order (random.getrandbits(32 * m)
-// split little-endian); out: int32 [calls][out_stride]; returns the number of words consumed, or -1 if `n_words` did not
-// suffice, -2 if n is not in the range where CPython uses this algorithm.  Host code (index logic, no compute).
+// The rows `random.sample(memory, k)` picks from a list of n transitions (base/core/replay_memory.py:72-73, 83-85), for `calls`
+// consecutive calls, replayed from the raw 32-bit outputs of the generator.  CPython's sample() draws j = _randbelow(m)
+// = getrandbits(m.bit_length()) -- one 32-bit output shifted right -- rejected while >= m; for n above its set-size threshold
+// (21 + 4 ** ceil(log4(3 k)) for k > 5) it draws from m = n and rejects a j it already holds, below it draws from a shrinking
+// pool (m = n - i, result[i] = pool[j], pool[j] = pool[m - 1]).  words: the next outputs of the Mersenne Twister in order
+// (random.getrandbits(32 * m) split little-endian); out: int32 [calls][out_stride]; returns the number of words consumed, or
+// -1 if `n_words` did not suffice, -2 for bad arguments.  Host code (index logic, no compute).
 long long serl_host_sample_slots(const uint32_t *words, long long n_words, int32_t n, int32_t k, int32_t calls, int32_t *out,
                                  int32_t out_stride)
 {
-  if (!words || !out || n <= 0 || k <= 0 || k > n || calls < 0) return -2;
-  // random.sample: setsize = 21; if k > 5: setsize += 4 ** ceil(log(k * 3, 4)); the set-based branch needs n > setsize
+  if (!words || !out || n <= 0 || k <= 0 || k > n || calls < 0 || out_stride < k) return -2;
   long long setsize = 21;
   if (k > 5) {
     long long pw = 1;
     while (pw < 3LL * k) pw *= 4;
     setsize += pw;
   }
-  if ((long long)n <= setsize) return -2;
-  int bits = 0;
-  for (uint32_t v = (uint32_t)n; v; v >>= 1) ++bits;
-  const int shift = 32 - bits;
+  auto bit_length = [](uint32_t v) { int b = 0; for (; v; v >>= 1) ++b; return b; };
   long long pos = 0;
+  if ((long long)n <= setsize) {                       // pool branch
+    int32_t *pool = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    if (!pool) return -2;
+    for (int c = 0; c < calls; ++c) {
+      int32_t *o = out + (size_t)c * out_stride;
+      for (int i = 0; i < n; ++i) pool[i] = i;
+      for (int i = 0; i < k; ++i) {
+        const uint32_t m = (uint32_t)(n - i);
+        const int shift = 32 - bit_length(m);
+        uint32_t j;
+        do {
+          if (pos >= n_words) { free(pool); return -1; }
+          j = words[pos++] >> shift;
+        } while (j >= m);
+        o[i] = pool[j];
+        pool[j] = pool[m - 1];
+      }
+    }
+    free(pool);
+    return pos;
+  }
+  const int shift = 32 - bit_length((uint32_t)n);
   unsigned char *seen = (unsigned char *)calloc((size_t)n, 1);
   if (!seen) return -2;
   for (int c = 0; c < calls; ++c) {

@@ -77,36 +77,10 @@ def distilation_crossover(args, engine, spec, weights, first, second, buffers, c
 # ---- all distillations of an epoch in one launch ----------------------------------------------------------------------
 
 def sample_minibatches(n, k, calls, rng=random):
-    """`calls` consecutive `rng.sample(range(n), k)` -> int32 [calls, 128] (first k columns), consuming the generator exactly
-    like the python calls would.  The draws of a whole distillation (750 calls) cost ~50 ms of interpreter time one by one;
-    here the raw 32-bit outputs of the Mersenne Twister are taken in bulk (getrandbits) and CPython's selection algorithm
-    is replayed by a few lines of C (serl_host_sample_slots), after which the generator is rewound and advanced by the
-    number of outputs the python calls would have consumed."""
-    import ctypes
+    """`calls` consecutive `rng.sample(range(n), k)` -> int32 [calls, 128] (first k columns): replay.sample_many"""
     import numpy as np
-    from . import _capi
     out = np.zeros((calls, 128), dtype=np.int32)
-    if calls == 0:
-        return out
-    fast = all(hasattr(rng, f) for f in ('getstate', 'setstate', 'getrandbits'))
-    if fast:
-        L = _capi.lib()
-        bits = int(n).bit_length()
-        m = int(calls * k * (2 ** bits / n) * 1.25) + 4096
-        state = rng.getstate()
-        while True:
-            words = np.frombuffer(rng.getrandbits(32 * m).to_bytes(4 * m, 'little'), dtype='<u4')
-            used = int(L.serl_host_sample_slots(words.ctypes.data, m, int(n), int(k), int(calls), out.ctypes.data, 128))
-            rng.setstate(state)
-            if used == -1:
-                m *= 2
-                continue
-            break
-        if used > 0:
-            rng.getrandbits(32 * used)
-            return out
-    for c in range(calls):                      # small buffers (CPython's pool-based branch) or a foreign generator
-        out[c, :k] = rng.sample(range(n), k)
+    out[:, :k] = replay.sample_many(n, k, calls, rng)
     return out
 
 

@@ -170,6 +170,45 @@ def proximal_mutate(engine, weights, member, spec: NetSpec, mag, buffer, batch_s
     return scaling
 
 
+class ProximalBatch:
+    """Several proximal / safe mutations of one epoch applied together: `add` makes a member's host draws right away, in the
+    reference's order (its minibatch from python `random`, its delta from torch's generator); `apply` computes all
+    sensitivities in ONE serl_ga_sensitivity launch per batch size (one workgroup per member, side by side instead of one
+    after the other) and perturbs the rows.  A mutation only reads and writes its own member."""
+
+    def __init__(self, engine, weights, spec: NetSpec, mag, batch_size, rng=random):
+        self.engine, self.weights, self.spec, self.mag, self.batch_size, self.rng = engine, weights, spec, mag, int(batch_size), rng
+        self.items = []
+
+    def add(self, member, buffer, critical_buffer=None):
+        src = buffer
+        if critical_buffer is not None and len(critical_buffer) > 1:           # safe_mutate, mod_neuro_evo.py:258-261
+            src = critical_buffer
+        states = src.sample(min(self.batch_size, len(src)), self.rng)[0]
+        self.items.append((int(member), states, draw_delta(self.spec, self.mag)))
+
+    def apply(self):
+        if not self.items:
+            return
+        dev = self.weights.device
+        by_size = {}
+        for k, (_, st, _) in enumerate(self.items):
+            by_size.setdefault(st.shape[0], []).append(k)
+        scal = [None] * len(self.items)
+        for B, ks in by_size.items():
+            sc = sensitivity(self.engine, self.weights, [self.items[k][0] for k in ks], self.spec, torch.stack([self.items[k][1] for k in ks]))
+            for j, k in enumerate(ks):
+                scal[k] = sc[j]
+        deltas = torch.stack([d for _, _, d in self.items]).to(dev)
+        segs = self.spec.genome_segments()
+        so, sl = _i32(dev, [s_[0] for s_ in segs]), _i32(dev, [s_[1] for s_ in segs])
+        for k, (member, _, _) in enumerate(self.items):
+            _capi.check(self.engine.lib.serl_ga_scaled_perturb(self.engine.ctx, self.weights.data_ptr(), self.weights.stride(0), member,
+                                                               so.data_ptr(), sl.data_ptr(), len(segs), deltas[k].data_ptr(),
+                                                               scal[k].contiguous().data_ptr(), _stream(dev)), 'serl_ga_scaled_perturb')
+        self.items = []
+
+
 def safe_mutate(engine, weights, member, spec: NetSpec, mag, buffer, critical_buffer, batch_size, rng=random, delta=None):
     src = critical_buffer if len(critical_buffer) > 1 else buffer          # mod_neuro_evo.py:258-261
     return proximal_mutate(engine, weights, member, spec, mag, src, batch_size, rng, delta)
@@ -195,18 +234,40 @@ def sort_groups_by_distance(engine, weights, genomes, buffers, spec: NetSpec, rn
     get_distance = gene1.get_novelty(batch of gene2) + gene2.get_novelty(batch of gene1), batches of
     min(256, len(buffer1), len(buffer2)) from the latest 1000 tuples of each buffer (same python `random` draws, in the
     reference's order); all 2 * pairs forward batches in ONE launch.  -> [(second, first, distance)] sorted descending."""
-    pairs, members, st, ac = [], [], [], []
+    from . import replay
+    pairs, members, calls = [], [], []
     for i, first in enumerate(genomes):
         for second in genomes[i + 1:]:
             b1, b2 = buffers[first], buffers[second]
             bs = min(256, min(len(b1), len(b2)))
-            s1, a1, _, _, _ = b1.sample_from_latest(bs, 1000, rng)
-            s2, a2, _, _, _ = b2.sample_from_latest(bs, 1000, rng)
+            calls += [(b1, bs), (b2, bs)]                  # sample_from_latest(bs, 1000) of gene1's, then of gene2's buffer
             pairs.append((second, first, bs))
             members += [first, second]                     # gene1 judged on gene2's batch, gene2 on gene1's
-            st += [s2, s1]; ac += [a2, a1]
     if not pairs:
         return []
+    # the draws, in the reference's order; runs of calls with the same (len(latest), batch) are replayed in bulk
+    latest = {}
+    for ring, _ in calls:
+        if id(ring) not in latest:
+            latest[id(ring)] = ring.latest_slots(1000)
+    picks, k0 = [None] * len(calls), 0
+    while k0 < len(calls):
+        n0, bs0 = len(latest[id(calls[k0][0])]), calls[k0][1]
+        k1 = k0
+        while k1 < len(calls) and (len(latest[id(calls[k1][0])]), calls[k1][1]) == (n0, bs0):
+            k1 += 1
+        got = replay.sample_many(n0, bs0, k1 - k0, rng)
+        for k in range(k0, k1):
+            picks[k] = got[k - k0]
+        k0 = k1
+    batches = []
+    for (ring, _), pick in zip(calls, picks):
+        rows = ring.rows[torch.from_numpy(latest[id(ring)][pick.astype(np.int64)]).to(ring.device)]
+        batches.append(ring.split(rows))
+    st, ac = [], []
+    for k in range(len(pairs)):
+        (s1, a1, _, _, _), (s2, a2, _, _, _) = batches[2 * k], batches[2 * k + 1]
+        st += [s2, s1]; ac += [a2, a1]
     sizes = {p[2] for p in pairs}
     if len(sizes) == 1:
         nov = novelty(engine, weights, members, spec, torch.stack(st), torch.stack(ac)).cpu().numpy().astype(np.float64)

@@ -19,6 +19,37 @@ import torch
 ROW = 20          # obs7 | action3 | next_obs7 | reward | done | cost
 
 
+def sample_many(n, k, calls, rng=random):
+    """`calls` consecutive `rng.sample(range(n), k)` -> int32 [calls, k], consuming the generator exactly like the python
+    calls would.  One call at a time costs ~50 - 100 us of interpreter time (a distillation draws 750 minibatches, the
+    distance sort of an epoch ~1 000); here the raw 32-bit outputs of the Mersenne Twister are taken in bulk (getrandbits),
+    CPython's selection algorithm is replayed by a few lines of C (serl_host_sample_slots), and the generator is rewound
+    and advanced by the number of outputs the python calls would have consumed."""
+    from . import _capi
+    out = np.zeros((calls, k), dtype=np.int32)
+    if calls == 0 or k == 0:
+        return out
+    if calls >= 2 and all(hasattr(rng, f) for f in ('getstate', 'setstate', 'getrandbits')):
+        L = _capi.lib()
+        m = int(calls * k * 2.2) + 4096
+        state = rng.getstate()
+        while True:
+            words = np.frombuffer(rng.getrandbits(32 * m).to_bytes(4 * m, 'little'), dtype='<u4')
+            used = int(L.serl_host_sample_slots(words.ctypes.data, m, int(n), int(k), int(calls), out.ctypes.data, int(k)))
+            rng.setstate(state)
+            if used == -1:
+                m *= 2
+                continue
+            break
+        if used >= 0:
+            if used:
+                rng.getrandbits(32 * used)
+            return out
+    for c in range(calls):                      # a single call, or a foreign generator
+        out[c] = rng.sample(range(n), k)
+    return out
+
+
 class DeviceReplay:
     """Uniform replay ring on the GPU with the interface of replay_memory.ReplayMemory."""
 
@@ -64,19 +95,20 @@ class DeviceReplay:
     def latest_slots(self, latest):
         """physical slots of ReplayMemory.get_latest(latest) (replay_memory.py:42-56), most recent last"""
         n, p, cap = self.size, self.position, self.capacity
-        mem = list(range(n))
+        mem = np.arange(n, dtype=np.int64)
+        latest = int(latest)
         if cap < latest:
-            out = mem[p:] + mem[:p]
+            out = np.concatenate([mem[p:], mem[:p]])
         elif n < cap:
-            out = mem[-latest:]
+            out = mem[-latest:] if latest else mem
         elif p >= latest:
-            out = mem[:p][-latest:]
+            out = mem[:p][-latest:] if latest else mem[:p]
         else:
-            out = mem[-latest + p:] + mem[:p]
+            out = np.concatenate([mem[-latest + p:], mem[:p]])
         return out
 
     def get_latest(self, latest):
-        return self.rows[torch.as_tensor(self.latest_slots(latest), dtype=torch.int64, device=self.device)]
+        return self.rows[torch.from_numpy(self.latest_slots(latest)).to(self.device)]
 
     def add_content_of(self, other):
         self.append_rows(other.get_latest(self.capacity))
@@ -107,7 +139,7 @@ class DeviceReplay:
     def sample_from_latest(self, batch_size, latest, rng=random):
         slots = self.latest_slots(latest)
         pick = rng.sample(range(len(slots)), batch_size)
-        return self.split(self.rows[torch.as_tensor([slots[i] for i in pick], dtype=torch.int64, device=self.device)])
+        return self.split(self.rows[torch.from_numpy(slots[np.asarray(pick, dtype=np.int64)]).to(self.device)])
 
 
 class _Job(ctypes.Structure):

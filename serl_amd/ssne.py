@@ -235,7 +235,18 @@ class SSNE:
                     off_j = rng.choice(others)
                     child = self.distilation_crossover(weights, int(i), int(off_j), buffers)
                     self.clone(weights, -1, int(i), buffers, critical, master_rings=child)
+        # mutations: a member's draws happen when its turn comes (the reference's order); the Jacobian-based ones are applied
+        # together afterwards (ga.ProximalBatch: one sensitivity launch for all of them)
+        batch = None
+        if self.mut_type in ('proximal', 'safe') and weights is not None:
+            batch = ga.ProximalBatch(self.engine, weights, self.spec, self.args.mutation_mag, self.args.mutation_batch_size, random)
         for i in index_rank[self.num_elitists:]:
             if rng.random() < self.args.mutation_prob:
-                self.mutate(weights, int(i), buffers, critical)
+                if batch is None:
+                    self.mutate(weights, int(i), buffers, critical)
+                else:
+                    self._rec(2, int(i), -1)
+                    batch.add(int(i), buffers[i], critical[i] if self.mut_type == 'safe' else None)
+        if batch is not None:
+            batch.apply()
         return int(new_elitists[0])

@@ -83,6 +83,9 @@ ep_ms = []
 if '--epoch' in sys.argv:
     fit = np.random.default_rng(1).normal(-150, 50, 50)
     epoch(fit)
+    if '--profile-epoch' in sys.argv:
+        pr = cProfile.Profile(); pr.enable(); epoch(fit); pr.disable()
+        s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(45); print(s.getvalue()[:9000])
     ep_ms = [epoch(fit) * 1e3 for _ in range(3)]
 mean = {k: float(np.mean([t[k] for t in ts])) * 1e3 for k in ts[0]}
 total = mean['refs'] + mean['evaluate_generation'] + mean['validate_champion'] + mean['validate_rl']
