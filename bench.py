@@ -261,7 +261,7 @@ def main():
         'value_host_buffers': value_host,      # this rank, inputs crossing PCIe per evaluation (informational)
     }
     res.update(res_extra)
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:          # (the contract: the CPU baseline leg runs on rank 0 at N = 1 only)
         build_of = faults_of = None
         if mixed:
             rs_ = [builds.resolve_mode(m) for m in modes]
