@@ -13,14 +13,22 @@ def calc_smoothness(actions, lengths=None, dt=0.01):
     if lengths is None:
         lengths = torch.full((E,), T, dtype=torch.int64)
     lengths = torch.as_tensor(lengths).to(torch.int64).cpu().abs()
-    # episodes of many different lengths (a training generation): an FFT library plans -- rocFFT compiles -- per length;
-    # the direct-DFT kernel (csrc/serl_metrics.hip) takes them all in one launch.  Full-length batches keep the FFT (one
-    # plan per table length, made once).
-    uniq = torch.unique(lengths)
-    if actions.is_cuda and A == 3 and T <= 8192 and not (len(uniq) == 1 and int(uniq[0]) == T):
-        out = _smoothness_dft(actions, lengths, dt)
-        if out is not None:
-            return out
+    # Episodes that ran the whole table (length T: all of an evaluation's, usually) share ONE batched FFT whose plan is made
+    # once per process.  The others -- a training generation of untrained actors has ~150 distinct lengths, and an FFT
+    # library plans (rocFFT: compiles) per length, 0.7 s each -- go through the direct-DFT kernel (csrc/serl_metrics.hip)
+    # in one launch; its O(N^2) is why the full-length episodes do not (1 000 x 8 001 steps: 60 ms against 4).
+    if actions.is_cuda and A == 3 and T <= 8192:
+        short = torch.nonzero(lengths != T).flatten()
+        if len(short):
+            out = torch.empty(E, dtype=torch.float64, device=actions.device)
+            sub = actions if len(short) == E else actions.index_select(0, short.to(actions.device))
+            res = _smoothness_dft(sub, lengths[short], dt)
+            if res is not None:
+                out[short.to(actions.device)] = res
+                full = torch.nonzero(lengths == T).flatten()
+                if len(full):
+                    out[full.to(actions.device)] = calc_smoothness(actions.index_select(0, full.to(actions.device)), None, dt)
+                return out
     out = torch.empty(E, dtype=torch.float64, device=actions.device)
     for N in torch.unique(lengths).tolist():      # one batched FFT per distinct episode length
         idx = torch.nonzero(lengths == N).flatten().to(actions.device)
@@ -47,10 +55,11 @@ def _smoothness_dft(actions, lengths, dt):
     a = actions.contiguous()
     E, T, _ = a.shape
     n = lengths.to(torch.int32).to(a.device)
-    work = torch.empty(int(L.serl_smoothness_work_size(E, T)), dtype=torch.float64, device=a.device)
+    mx = max(int(lengths.max()), 4)                      # twiddle table / frequency chunks sized for the longest of them
+    work = torch.empty(int(L.serl_smoothness_work_size(E, mx)), dtype=torch.float64, device=a.device)
     out = torch.empty(E, dtype=torch.float64, device=a.device)
     stream = torch.cuda.current_stream(a.device).cuda_stream
-    _capi.check(L.serl_smoothness(eng.ctx, a.data_ptr(), T * 3, n.data_ptr(), E, T, float(dt), work.data_ptr(), out.data_ptr(),
+    _capi.check(L.serl_smoothness(eng.ctx, a.data_ptr(), T * 3, n.data_ptr(), E, mx, float(dt), work.data_ptr(), out.data_ptr(),
                                   ctypes.c_void_p(stream)), 'serl_smoothness')
     return out
 
