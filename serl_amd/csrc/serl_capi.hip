@@ -28,6 +28,7 @@ SERL_DECL_WAVE(nominal) SERL_DECL_WAVE(ice) SERL_DECL_WAVE(cg_timed) SERL_DECL_W
 #define SERL_DECL_TEAM(v)                                                                                     \
   void serl_launch_rollout_team_##v(const RolloutArgs &a, int grid, hipStream_t stream);                          \
   void serl_launch_rollout_teamx_##v(const RolloutArgs &a, int grid, hipStream_t stream);                         \
+  void serl_launch_rollout_teams_##v(const RolloutArgs &a, int grid, hipStream_t stream);                         \
   void serl_launch_dyn_team_##v(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
 SERL_DECL_TEAM(nominal) SERL_DECL_TEAM(ice) SERL_DECL_TEAM(cg_timed) SERL_DECL_TEAM(gust) SERL_DECL_TEAM(test)
 
@@ -110,6 +111,18 @@ static bool serl_use_team(const serl_ctx *c, int code, int episodes)
 
 static void serl_launch_rollout_team(int code, const RolloutArgs &a, int grid, hipStream_t stream)
 {
+  // (rollout_device.h: serl_lds_actor_ok) shapes whose weights the actor wavefront streams have a kernel of their own
+  const bool lds_actor = a.d.hidden == 32 && a.d.num_layers <= 3 && a.d.state_dim == 7 && a.d.action_dim == 3;
+  if (!lds_actor) {
+    switch (code) {
+      case SERL_DYN_NOMINAL: serl_launch_rollout_teams_nominal(a, grid, stream); break;
+      case SERL_DYN_ICE: serl_launch_rollout_teams_ice(a, grid, stream); break;
+      case SERL_DYN_CG_TIMED: serl_launch_rollout_teams_cg_timed(a, grid, stream); break;
+      case SERL_DYN_GUST: serl_launch_rollout_teams_gust(a, grid, stream); break;
+      default: serl_launch_rollout_teams_test(a, grid, stream); break;
+    }
+    return;
+  }
   switch (code) {
     case SERL_DYN_NOMINAL: serl_launch_rollout_team_nominal(a, grid, stream); break;
     case SERL_DYN_ICE: serl_launch_rollout_team_ice(a, grid, stream); break;
