@@ -281,6 +281,18 @@ static __device__ __forceinline__ void citw_lookup2d(const int wv, const CitwLoo
   for (int base = 0; base < COUNT; base += CITW_GROUP_LANES) citw_lookup2d_pass(wv, L, out, lane + base);
 }
 
+// The passes PART, PART + NPARTS, ... of a 2-D round: with fewer lanes per episode than tables (two / four episodes per team)
+// the passes are independent and the team's idle helpers take some of them beside wave 0 (gen/citation_<v>_team.inc)
+#ifndef CITW_L2_SHARE
+#define CITW_L2_SHARE (64 / CITW_GROUP_LANES)
+#endif
+template <int COUNT, int PART, int NPARTS, typename OUT>
+static __device__ __forceinline__ void citw_lookup2d_part(const int wv, const CitwLookup *L, OUT &out, int lane)
+{
+#pragma unroll
+  for (int base = PART * CITW_GROUP_LANES; base < COUNT; base += NPARTS * CITW_GROUP_LANES) citw_lookup2d_pass(wv, L, out, lane + base);
+}
+
 template <typename OUT>
 static __device__ __forceinline__ void citw_lookup2d_pass(const int wv, const CitwLookup *L, OUT &out, int lane)
 {

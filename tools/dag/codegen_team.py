@@ -54,6 +54,7 @@ POST_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_POST_BIAS', '0').split(
 AFFINITY_POST = float(os.environ.get('CITW_TEAM_AFFINITY_POST', 0.0))
 SHARE_LIBM = int(os.environ.get('CITW_TEAM_SHARE_LIBM', 1))           # 1: every libm call is made by one wave, the others read the result (flag hand-over)
 SPREAD_IN = int(os.environ.get('CITW_TEAM_SPREAD_INPUTS', 0))         # 1: EVERY round-1 input cone runs on a helper; wave 0 waits for their input flags (g_iflag), then looks up
+SHARE_2D = int(os.environ.get('CITW_TEAM_SHARE_2D', 1))            # 1: with several episodes per team (lane groups) the passes of round 1's 2-D interpolation are shared with helper waves 2, 4, 6 (CITW_L2_SHARE)
 OFFLOAD_1D = int(os.environ.get('CITW_TEAM_OFFLOAD_1D', 1))          # 1: the 1-D interpolation pass of round 1 runs on helper wave 1 (after wave 0's index search, by flag) beside wave 0's 2-D pass
 SPREAD_MIN = float(os.environ.get('CITW_TEAM_SPREAD_MIN', 0))         # with SPREAD_INPUTS: only input cones at least this heavy (units) leave wave 0
 SIMD_PAIRS = int(os.environ.get('CITW_TEAM_SIMD_PAIRS', 0))            # 1: the balancer counts the load of a SIMD (waves b and b + 4 share one) instead of a wave's
@@ -146,6 +147,7 @@ class TeamGen(codegen.Gen):
         have = [set(A0w)] + [set() for _ in range(K - 1)]
         load = [sum(cost(m) for m in A0w) + fn_cost(A0w, 0, True) + LOOKUP_PHASES] + [0.0] * (K - 1)
         self.h1d = 1 if (OFFLOAD_1D and K > 2 and self.rounds[0]['L1']) else None
+        self.l2_helpers = [2, 4, 6] if (SHARE_2D and K >= 7 and self.h1d is not None and self.rounds[0]['L2']) else []
         if self.h1d is not None:
             load[self.h1d] += 220.0            # the 1-D pass it takes over from wave 0
             load[0] -= 220.0
@@ -475,7 +477,9 @@ class TeamGen(codegen.Gen):
                     B('  citw_iflag_raise(0, %s);   /* interval indices are in g_sidx[0]: wave %d runs the 1-D pass beside the 2-D pass */' % (SEQ, self.h1d))
                 if r == 0:
                     B('  %s;' % TM(6))
-                if R['L2']:
+                if R['L2'] and r == 0 and self.l2_helpers:
+                    B('  citw_lookup2d_part<%d, 0, CITW_L2_SHARE>(wv, L[%d][0], g_out%d, lane);   /* (lane groups: waves %s take the other passes) */' % (len(R['L2']), r, r, self.l2_helpers))
+                elif R['L2']:
                     B('  citw_lookup2d<%d>(wv, L[%d][0], g_out%d, lane);' % (len(R['L2']), r, r))
                 if r == 0:
                     B('  %s;' % TM(7))
@@ -574,6 +578,12 @@ class TeamGen(codegen.Gen):
                 for i in pre_x:
                     B('    g_f[0][stage][%d] = %s;' % (i, self.ref(self.xdot[i])))
                 B('  }')
+            if b in self.l2_helpers:
+                k = self.l2_helpers.index(b) + 1
+                B('#if CITW_L2_SHARE > %d   /* several episodes per team: pass %d (of every CITW_L2_SHARE) of round 1\'s 2-D interpolation, beside wave 0 */' % (k, k))
+                B('  citw_iflag_wait(0, %s);' % SEQ)
+                B('  citw_lookup2d_part<%d, %d, CITW_L2_SHARE>(0, L[0][0], g_out0, lane);' % (len(self.rounds[0]['L2']), k))
+                B('#endif')
             if b != 0 and b == self.h1d:
                 B('  /* ---- the 1-D interpolation pass of round 1, taken over from wave 0 */')
                 B('  citw_iflag_wait(0, %s);' % SEQ)
@@ -632,7 +642,7 @@ class TeamGen(codegen.Gen):
             text = re.sub(r'\b(g_xs|g_out0|g_out1|g_in|g_dw|g_cmd|g_f)\[0\]', r'\1[CITW_TROW]', text)
             text = re.sub(r'\bg_m\[(\d+)\]', r'g_m[CITW_MROW(\1)]', text)
             text = re.sub(r'\bg_x\[(\d+)\]', r'g_x[CITW_XOFF + \1]', text)
-            text = re.sub(r'\b(citw_search<[^>]*>|citw_lookup2d<\d+>|citw_lookup1d<\d+>)\(0, ', r'\1(CITW_TROW, ', text)
+            text = re.sub(r'\b(citw_search<[^>]*>|citw_lookup2d<\d+>|citw_lookup2d_part<[^>]*>|citw_lookup1d<\d+>)\(0, ', r'\1(CITW_TROW, ', text)
             text = text.replace('const int lane = threadIdx.x & 63;', 'const int lane = CITW_LANE;')
             return text
 
