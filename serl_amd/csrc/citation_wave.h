@@ -227,6 +227,18 @@ static __device__ __forceinline__ void citw_search(const int wv, const CitwSearc
   for (int base = 0; base < COUNT; base += CITW_GROUP_LANES) citw_search_pass<MAXN>(wv, S, lane + base);
 }
 
+// The passes PART, PART + NPARTS, ... of a search round (several episodes per team: helper wavefronts take passes beside wave 0)
+#ifndef CITW_L2_SHARE
+#define CITW_L2_SHARE (64 / CITW_GROUP_LANES)
+#endif
+#define CITW_SEARCH_SHARE(count) (((count) + CITW_GROUP_LANES - 1) / CITW_GROUP_LANES < 3 ? ((count) + CITW_GROUP_LANES - 1) / CITW_GROUP_LANES : 3)
+template <int MAXN, int COUNT, int PART, int NPARTS>
+static __device__ __forceinline__ void citw_search_part(const int wv, const CitwSearch *S, int lane)
+{
+#pragma unroll
+  for (int base = PART * CITW_GROUP_LANES; base < COUNT; base += NPARTS * CITW_GROUP_LANES) citw_search_pass<MAXN>(wv, S, lane + base);
+}
+
 template <int MAXN>
 static __device__ __forceinline__ void citw_search_pass(const int wv, const CitwSearch *S, int lane)
 {

@@ -54,6 +54,7 @@ POST_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_POST_BIAS', '0').split(
 AFFINITY_POST = float(os.environ.get('CITW_TEAM_AFFINITY_POST', 0.0))
 SHARE_LIBM = int(os.environ.get('CITW_TEAM_SHARE_LIBM', 1))           # 1: every libm call is made by one wave, the others read the result (flag hand-over)
 SPREAD_IN = int(os.environ.get('CITW_TEAM_SPREAD_INPUTS', 0))         # 1: EVERY round-1 input cone runs on a helper; wave 0 waits for their input flags (g_iflag), then looks up
+SHARE_SEARCH = int(os.environ.get('CITW_TEAM_SHARE_SEARCH', 0))    # 1: ... and the passes of round 1's index search with waves 2, 4 (measured SLOWER: four per team 26.8 -> 28.4 us; the hand-overs cost more than two passes)
 SHARE_2D = int(os.environ.get('CITW_TEAM_SHARE_2D', 1))            # 1: with several episodes per team (lane groups) the passes of round 1's 2-D interpolation are shared with helper waves 2, 4, 6 (CITW_L2_SHARE)
 OFFLOAD_1D = int(os.environ.get('CITW_TEAM_OFFLOAD_1D', 1))          # 1: the 1-D interpolation pass of round 1 runs on helper wave 1 (after wave 0's index search, by flag) beside wave 0's 2-D pass
 SPREAD_MIN = float(os.environ.get('CITW_TEAM_SPREAD_MIN', 0))         # with SPREAD_INPUTS: only input cones at least this heavy (units) leave wave 0
@@ -472,9 +473,22 @@ class TeamGen(codegen.Gen):
                             B('  citw_flag_wait(%d, %s);   /* the input(s) wave %d computes are in g_in[0] */' % (self.P, SEQ, self.P))
                             waited.add(self.P)
                         B('  %s;' % TM(9))
+                if r == 0 and self.l2_helpers and SHARE_SEARCH:
+                    ns = len(R['searches'])
+                    B('#if CITW_SEARCH_SHARE(%d) > 1   /* several episodes per team: the search passes are shared with waves 2 (and 4) */' % ns)
+                    B('  citw_iflag_raise(7, %s);   /* the look-up inputs are in g_in[0] */' % SEQ)
+                    B('  citw_search_part<%d, %d, 0, CITW_SEARCH_SHARE(%d)>(wv, S[%d], lane);' % (R['maxn'], ns, ns, r))
+                    B('  citw_iflag_raise(0, %s);' % SEQ)
+                    B('  citw_iflag_wait(2, %s);' % SEQ)
+                    B('#if CITW_SEARCH_SHARE(%d) > 2' % ns)
+                    B('  citw_iflag_wait(4, %s);' % SEQ)
+                    B('#endif')
+                    B('#else')
                 B('  citw_search<%d, %d>(wv, S[%d], lane);' % (R['maxn'], len(R['searches']), r))
                 if r == 0 and self.h1d is not None:
                     B('  citw_iflag_raise(0, %s);   /* interval indices are in g_sidx[0]: wave %d runs the 1-D pass beside the 2-D pass */' % (SEQ, self.h1d))
+                if r == 0 and self.l2_helpers and SHARE_SEARCH:
+                    B('#endif')
                 if r == 0:
                     B('  %s;' % TM(6))
                 if R['L2'] and r == 0 and self.l2_helpers:
@@ -578,15 +592,36 @@ class TeamGen(codegen.Gen):
                 for i in pre_x:
                     B('    g_f[0][stage][%d] = %s;' % (i, self.ref(self.xdot[i])))
                 B('  }')
+            ns0 = len(self.rounds[0]['searches'])
+            R0 = self.rounds[0]
+
+            def wait_searches(me):
+                """every wave that reads g_sidx waits for the waves that filled it"""
+                B('  citw_iflag_wait(0, %s);' % SEQ)
+                if self.l2_helpers and SHARE_SEARCH:
+                    if me != 2:
+                        B('#if CITW_SEARCH_SHARE(%d) > 1' % ns0)
+                        B('  citw_iflag_wait(2, %s);' % SEQ)
+                        B('#endif')
+                    if me != 4:
+                        B('#if CITW_SEARCH_SHARE(%d) > 2' % ns0)
+                        B('  citw_iflag_wait(4, %s);' % SEQ)
+                        B('#endif')
             if b in self.l2_helpers:
                 k = self.l2_helpers.index(b) + 1
+                if SHARE_SEARCH and k <= 2:
+                    B('#if CITW_SEARCH_SHARE(%d) > %d   /* several episodes per team: search pass %d, beside wave 0 */' % (ns0, k, k))
+                    B('  citw_iflag_wait(7, %s);' % SEQ)
+                    B('  citw_search_part<%d, %d, %d, CITW_SEARCH_SHARE(%d)>(0, S[0], lane);' % (R0['maxn'], ns0, k, ns0))
+                    B('  citw_iflag_raise(%d, %s);' % (b, SEQ))
+                    B('#endif')
                 B('#if CITW_L2_SHARE > %d   /* several episodes per team: pass %d (of every CITW_L2_SHARE) of round 1\'s 2-D interpolation, beside wave 0 */' % (k, k))
-                B('  citw_iflag_wait(0, %s);' % SEQ)
+                wait_searches(b)
                 B('  citw_lookup2d_part<%d, %d, CITW_L2_SHARE>(0, L[0][0], g_out0, lane);' % (len(self.rounds[0]['L2']), k))
                 B('#endif')
             if b != 0 and b == self.h1d:
                 B('  /* ---- the 1-D interpolation pass of round 1, taken over from wave 0 */')
-                B('  citw_iflag_wait(0, %s);' % SEQ)
+                wait_searches(b)
                 B('  citw_lookup1d<%d>(0, L[0][1], g_out0, lane);' % len(self.rounds[0]['L1']))
             B('  %s;' % TM(0))
             B('  __syncthreads();   /* B1: look-up results (g_out0) and exchanged values (g_x) are visible to every wave */')
@@ -642,7 +677,7 @@ class TeamGen(codegen.Gen):
             text = re.sub(r'\b(g_xs|g_out0|g_out1|g_in|g_dw|g_cmd|g_f)\[0\]', r'\1[CITW_TROW]', text)
             text = re.sub(r'\bg_m\[(\d+)\]', r'g_m[CITW_MROW(\1)]', text)
             text = re.sub(r'\bg_x\[(\d+)\]', r'g_x[CITW_XOFF + \1]', text)
-            text = re.sub(r'\b(citw_search<[^>]*>|citw_lookup2d<\d+>|citw_lookup2d_part<[^>]*>|citw_lookup1d<\d+>)\(0, ', r'\1(CITW_TROW, ', text)
+            text = re.sub(r'\b(citw_search<[^>]*>|citw_search_part<[^>]*>|citw_lookup2d<\d+>|citw_lookup2d_part<[^>]*>|citw_lookup1d<\d+>)\(0, ', r'\1(CITW_TROW, ', text)
             text = text.replace('const int lane = threadIdx.x & 63;', 'const int lane = CITW_LANE;')
             return text
 
