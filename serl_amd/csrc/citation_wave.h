@@ -334,6 +334,15 @@ static __device__ __forceinline__ void citw_lookup1d(const int wv, const CitwLoo
   for (int base = 0; base < COUNT; base += CITW_GROUP_LANES) citw_lookup1d_pass(wv, L, out, lane + base);
 }
 
+// ... and of a 1-D round (two wavefronts at most)
+#define CITW_L1_SHARE(count) (((count) + CITW_GROUP_LANES - 1) / CITW_GROUP_LANES < 2 ? 1 : 2)
+template <int COUNT, int PART, int NPARTS, typename OUT>
+static __device__ __forceinline__ void citw_lookup1d_part(const int wv, const CitwLookup *L, OUT &out, int lane)
+{
+#pragma unroll
+  for (int base = PART * CITW_GROUP_LANES; base < COUNT; base += NPARTS * CITW_GROUP_LANES) citw_lookup1d_pass(wv, L, out, lane + base);
+}
+
 template <typename OUT>
 static __device__ __forceinline__ void citw_lookup1d_pass(const int wv, const CitwLookup *L, OUT &out, int lane)
 {

@@ -55,6 +55,7 @@ AFFINITY_POST = float(os.environ.get('CITW_TEAM_AFFINITY_POST', 0.0))
 SHARE_LIBM = int(os.environ.get('CITW_TEAM_SHARE_LIBM', 1))           # 1: every libm call is made by one wave, the others read the result (flag hand-over)
 SPREAD_IN = int(os.environ.get('CITW_TEAM_SPREAD_INPUTS', 0))         # 1: EVERY round-1 input cone runs on a helper; wave 0 waits for their input flags (g_iflag), then looks up
 SHARE_SEARCH = int(os.environ.get('CITW_TEAM_SHARE_SEARCH', 0))    # 1: ... and the passes of round 1's index search with waves 2, 4 (measured SLOWER: four per team 26.8 -> 28.4 us; the hand-overs cost more than two passes)
+SHARE_1D = int(os.environ.get('CITW_TEAM_SHARE_1D', 0))            # 1: ... and the second pass of the 1-D interpolation (16 lanes per episode) runs on wave 3 beside wave 1's first (measured: no change, 26.80 against 26.78 us)
 SHARE_2D = int(os.environ.get('CITW_TEAM_SHARE_2D', 1))            # 1: with several episodes per team (lane groups) the passes of round 1's 2-D interpolation are shared with helper waves 2, 4, 6 (CITW_L2_SHARE)
 OFFLOAD_1D = int(os.environ.get('CITW_TEAM_OFFLOAD_1D', 1))          # 1: the 1-D interpolation pass of round 1 runs on helper wave 1 (after wave 0's index search, by flag) beside wave 0's 2-D pass
 SPREAD_MIN = float(os.environ.get('CITW_TEAM_SPREAD_MIN', 0))         # with SPREAD_INPUTS: only input cones at least this heavy (units) leave wave 0
@@ -619,10 +620,20 @@ class TeamGen(codegen.Gen):
                 wait_searches(b)
                 B('  citw_lookup2d_part<%d, %d, CITW_L2_SHARE>(0, L[0][0], g_out0, lane);' % (len(self.rounds[0]['L2']), k))
                 B('#endif')
+            if b == 3 and self.h1d is not None and self.l2_helpers and SHARE_1D:
+                n1 = len(self.rounds[0]['L1'])
+                B('#if CITW_L1_SHARE(%d) > 1   /* 16 lanes per episode: the second pass of the 1-D interpolation, beside wave 1 */' % n1)
+                wait_searches(b)
+                B('  citw_lookup1d_part<%d, 1, 2>(0, L[0][1], g_out0, lane);' % n1)
+                B('#endif')
             if b != 0 and b == self.h1d:
                 B('  /* ---- the 1-D interpolation pass of round 1, taken over from wave 0 */')
                 wait_searches(b)
-                B('  citw_lookup1d<%d>(0, L[0][1], g_out0, lane);' % len(self.rounds[0]['L1']))
+                if self.l2_helpers and SHARE_1D:
+                    n1 = len(self.rounds[0]['L1'])
+                    B('  citw_lookup1d_part<%d, 0, CITW_L1_SHARE(%d)>(0, L[0][1], g_out0, lane);   /* (16 lanes per episode: wave 3 takes the second pass) */' % (n1, n1))
+                else:
+                    B('  citw_lookup1d<%d>(0, L[0][1], g_out0, lane);' % len(self.rounds[0]['L1']))
             B('  %s;' % TM(0))
             B('  __syncthreads();   /* B1: look-up results (g_out0) and exchanged values (g_x) are visible to every wave */')
             after_b1[0] = True
@@ -677,7 +688,7 @@ class TeamGen(codegen.Gen):
             text = re.sub(r'\b(g_xs|g_out0|g_out1|g_in|g_dw|g_cmd|g_f)\[0\]', r'\1[CITW_TROW]', text)
             text = re.sub(r'\bg_m\[(\d+)\]', r'g_m[CITW_MROW(\1)]', text)
             text = re.sub(r'\bg_x\[(\d+)\]', r'g_x[CITW_XOFF + \1]', text)
-            text = re.sub(r'\b(citw_search<[^>]*>|citw_search_part<[^>]*>|citw_lookup2d<\d+>|citw_lookup2d_part<[^>]*>|citw_lookup1d<\d+>)\(0, ', r'\1(CITW_TROW, ', text)
+            text = re.sub(r'\b(citw_search<[^>]*>|citw_search_part<[^>]*>|citw_lookup2d<\d+>|citw_lookup2d_part<[^>]*>|citw_lookup1d<\d+>|citw_lookup1d_part<[^>]*>)\(0, ', r'\1(CITW_TROW, ', text)
             text = text.replace('const int lane = threadIdx.x & 63;', 'const int lane = CITW_LANE;')
             return text
 
