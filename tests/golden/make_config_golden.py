@@ -15,6 +15,7 @@ reference signals itself (`init_ref`, phlabenv.py:303-345; the symmetric configu
       <c>_cost     info['cost'] of every step, int8 [T]
       <c>_u        env.last_u after every step (what Agent.evaluate collects for the smoothness), f64 [T, A]
       <c>_ret      [fitness, length (= info['t']), steps, smoothness]
+      <c>_mode     the env's mode string ('nominal', 'incremental', 'be', 'ice')
 
 Run in the build container (needs /root/reference):  python tests/golden/make_config_golden.py
 """
@@ -40,6 +41,9 @@ CASES = [  # name, configuration, mode, hidden, layers, activation, torch seed, 
     ('att_inc_soft', 'attitude', 'incremental', 32, 3, 'tanh', 24, 5114, True, 0.02),
     ('full_inc_n', 'full', 'incremental', 72, 3, 'relu', 15, 5105, True, 1.0),
     ('att_inc_n', 'attitude', 'incremental', 32, 3, 'elu', 16, 5106, True, 1.0),
+    # the other configurations on fault / off-nominal builds (the wrappers of envs/{be,ice}/citation.py see the padded command)
+    ('full_be', 'full', 'be', 32, 3, 'tanh', 17, 5107, False, 0.05),
+    ('sym_ice', 'symmetric', 'ice', 32, 3, 'tanh', 18, 5108, True, 0.05),
 ]
 
 
@@ -132,6 +136,7 @@ def main():
         for k, v in r.items():
             res['%s_%s' % (name, k)] = v
         res['%s_act' % name] = np.array(act)
+        res['%s_mode' % name] = np.array(mode)
         print(name, r['cfg'], r['ret'], 'cost steps', int(r['cost'].sum()), flush=True)
     np.savez_compressed(os.path.join(HERE, 'config.npz'), **res)
 

@@ -224,7 +224,7 @@ def test_make_evaluate_sequence_vs_reference_agent_evaluate(golden, oracle_engin
 
 
 CONFIG_SEEDS = {'sym': 5101, 'sym_soft': 5111, 'sym_inc_n': 5102, 'full': 5103, 'att_inc': 5104, 'att_inc_soft': 5114,
-                'full_inc_n': 5105, 'att_inc_n': 5106}
+                'full_inc_n': 5105, 'att_inc_n': 5106, 'full_be': 5107, 'sym_ice': 5108}
 
 
 def run_config_episode(golden, name, engine):
@@ -240,7 +240,7 @@ def run_config_episode(golden, name, engine):
     cfg, incr, S, Ad, H, L = (int(v) for v in g[name + '_cfg'])
     args = types.SimpleNamespace(state_dim=S, action_dim=Ad, hidden_size=H, num_layers=L, activation_actor=str(g[name + '_act']),
                                  smooth_fitness=False, noise_sd=0.2962183114680794, noise_clip=0.5)
-    mode = 'PHlab_%s_%s' % ({0: 'attitude', 1: 'symmetric', 2: 'full'}[cfg], 'incremental' if incr else 'nominal')
+    mode = 'PHlab_%s_%s' % ({0: 'attitude', 1: 'symmetric', 2: 'full'}[cfg], str(g[name + '_mode']))
     shared, counters = _ListBuf(), {}
     evaluate = serl_amd.make_evaluate(args, mode=mode, t_max=20, engine=engine, replay_buffer=shared, counters=counters)
     ag = serl_amd.GeneticAgent(args, buffer=_ListBuf(), critical_buffer=_ListBuf())

@@ -445,7 +445,7 @@ def test_elu_activation_spec_and_closed_loop_vs_reference(golden):
     assert (g['ret'][:, 3] < 2001).sum() == 2
 
 
-CONFIG_CASES = ['sym', 'sym_soft', 'sym_inc_n', 'full', 'att_inc', 'att_inc_soft', 'full_inc_n', 'att_inc_n']
+CONFIG_CASES = ['sym', 'sym_soft', 'sym_inc_n', 'full', 'att_inc', 'att_inc_soft', 'full_inc_n', 'att_inc_n', 'full_be', 'sym_ice']
 
 
 def config_case(g, name):
@@ -459,6 +459,13 @@ def config_case(g, name):
     return cfg, incr, net, rows, ref, (noise if np.any(noise) else None)
 
 
+def config_build(g, name):
+    """(build, fault rows) of a case's env mode: the fault wrappers act on the padded command whatever the configuration"""
+    from serl_amd import builds
+    build, row = builds.resolve_mode(str(g[name + '_mode']))
+    return build, (None if row == builds.NOMINAL_ROW else [list(row)])
+
+
 @pytest.mark.parametrize('name', CONFIG_CASES)
 def test_env_configurations_vs_reference_python(golden, name):
     """symmetric / full observation sets and incremental (rate) control, envs/phlabenv.py:84-97,174-176,205-220,377-380:
@@ -468,8 +475,9 @@ def test_env_configurations_vs_reference_python(golden, name):
     g = golden('config')
     cfg, incr, net, rows, ref, noise = config_case(g, name)
     S, A, T = net['state_dim'], net['action_dim'], len(rows)
+    build, faults = config_build(g, name)
     o = R.rollout(g[name + '_w'][None], net, [0], ref, t_max=20, action_noise=noise, traces=True, transitions=True,
-                  env_config=cfg, incremental=incr)
+                  env_config=cfg, incremental=incr, build=build, faults=faults)
     ret = g[name + '_ret']
     assert int(o['length_steps'][0]) == T == int(ret[2])
     assert o['length_t'][0] == ret[1]
