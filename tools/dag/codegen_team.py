@@ -54,6 +54,7 @@ POST_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_POST_BIAS', '0').split(
 AFFINITY_POST = float(os.environ.get('CITW_TEAM_AFFINITY_POST', 0.0))
 SHARE_LIBM = int(os.environ.get('CITW_TEAM_SHARE_LIBM', 1))           # 1: every libm call is made by one wave, the others read the result (flag hand-over)
 SPREAD_IN = int(os.environ.get('CITW_TEAM_SPREAD_INPUTS', 0))         # 1: EVERY round-1 input cone runs on a helper; wave 0 waits for their input flags (g_iflag), then looks up
+SEARCH_AT = float(os.environ.get('CITW_TEAM_SEARCH_AT', 1.0))         # where in a helper's own glue (fraction of its sinks) its shared search pass sits (1.0: behind all of it)
 SHARE_SEARCH = int(os.environ.get('CITW_TEAM_SHARE_SEARCH', 0))    # 1: ... and the passes of round 1's index search with waves 2, 4 (measured SLOWER: four per team 26.8 -> 28.4 us; the hand-overs cost more than two passes)
 SHARE_1D = int(os.environ.get('CITW_TEAM_SHARE_1D', 0))            # 1: ... and the second pass of the 1-D interpolation (16 lanes per episode) runs on wave 3 beside wave 1's first (measured: no change, 26.80 against 26.78 us)
 SHARE_2D = int(os.environ.get('CITW_TEAM_SHARE_2D', 1))            # 1: with several episodes per team (lane groups) the passes of round 1's 2-D interpolation are shared with helper waves 2, 4, 6 (CITW_L2_SHARE)
@@ -571,9 +572,21 @@ class TeamGen(codegen.Gen):
             if b == 0:
                 lookup_round(0, self.rounds[0], None)
                 done_rounds.add(0)
+            def emit_search_share(bb):
+                kq = self.l2_helpers.index(bb) + 1
+                nsq = len(self.rounds[0]['searches'])
+                B('#if CITW_SEARCH_SHARE(%d) > %d   /* several episodes per team: search pass %d, beside wave 0 */' % (nsq, kq, kq))
+                B('  citw_iflag_wait(7, %s);' % SEQ)
+                B('  citw_search_part<%d, %d, %d, CITW_SEARCH_SHARE(%d)>(0, S[0], lane);' % (self.rounds[0]['maxn'], nsq, kq, nsq))
+                B('  citw_iflag_raise(%d, %s);' % (bb, SEQ))
+                B('#endif')
             B('  /* ---- share of this wave in the look-up independent glue */')
             foreign = lambda n: any(m in shared and self.row_slot[m][0] != b for m in self.closure([n], self.S0))
-            for n in sorted(self.pre_sinks[b], key=lambda n: (foreign(n), self.pre_sinks[b].index(n))) if shared else self.pre_sinks[b]:
+            order = sorted(self.pre_sinks[b], key=lambda n: (foreign(n), self.pre_sinks[b].index(n))) if shared else self.pre_sinks[b]
+            search_at = int(len(order) * SEARCH_AT) if (b in self.l2_helpers[:2] and SHARE_SEARCH and SEARCH_AT < 1.0) else -1
+            for kk, n in enumerate(order):
+                if kk == search_at:
+                    emit_search_share(b)
                 emit_node(n, self.have[b])
             for n in self.exp[b]:
                 emit_node(n, self.have[b])
@@ -610,12 +623,8 @@ class TeamGen(codegen.Gen):
                         B('#endif')
             if b in self.l2_helpers:
                 k = self.l2_helpers.index(b) + 1
-                if SHARE_SEARCH and k <= 2:
-                    B('#if CITW_SEARCH_SHARE(%d) > %d   /* several episodes per team: search pass %d, beside wave 0 */' % (ns0, k, k))
-                    B('  citw_iflag_wait(7, %s);' % SEQ)
-                    B('  citw_search_part<%d, %d, %d, CITW_SEARCH_SHARE(%d)>(0, S[0], lane);' % (R0['maxn'], ns0, k, ns0))
-                    B('  citw_iflag_raise(%d, %s);' % (b, SEQ))
-                    B('#endif')
+                if SHARE_SEARCH and k <= 2 and SEARCH_AT >= 1.0:
+                    emit_search_share(b)
                 B('#if CITW_L2_SHARE > %d   /* several episodes per team: pass %d (of every CITW_L2_SHARE) of round 1\'s 2-D interpolation, beside wave 0 */' % (k, k))
                 wait_searches(b)
                 B('  citw_lookup2d_part<%d, %d, CITW_L2_SHARE>(0, L[0][0], g_out0, lane);' % (len(self.rounds[0]['L2']), k))
