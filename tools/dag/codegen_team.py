@@ -54,9 +54,11 @@ POST_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_POST_BIAS', '0').split(
 AFFINITY_POST = float(os.environ.get('CITW_TEAM_AFFINITY_POST', 0.0))
 SHARE_LIBM = int(os.environ.get('CITW_TEAM_SHARE_LIBM', 1))           # 1: every libm call is made by one wave, the others read the result (flag hand-over)
 SPREAD_IN = int(os.environ.get('CITW_TEAM_SPREAD_INPUTS', 0))         # 1: EVERY round-1 input cone runs on a helper; wave 0 waits for their input flags (g_iflag), then looks up
+L2_WAVES = [int(x) for x in os.environ.get('CITW_TEAM_L2_WAVES', '6,4,5').split(',')]           # the helper waves that take 2-D passes 1, 2, 3
+SEARCH_WAVES = [int(x) for x in os.environ.get('CITW_TEAM_SEARCH_WAVES', '1,3').split(',')]   # the helper waves that take search passes 1 (and 2)
 SEARCH_AT = float(os.environ.get('CITW_TEAM_SEARCH_AT', 1.0))         # where in a helper's own glue (fraction of its sinks) its shared search pass sits (1.0: behind all of it)
-SHARE_SEARCH = int(os.environ.get('CITW_TEAM_SHARE_SEARCH', 0))    # 1: ... and the passes of round 1's index search with waves 2, 4 (measured SLOWER: four per team 26.8 -> 28.4 us; the hand-overs cost more than two passes)
-SHARE_1D = int(os.environ.get('CITW_TEAM_SHARE_1D', 0))            # 1: ... and the second pass of the 1-D interpolation (16 lanes per episode) runs on wave 3 beside wave 1's first (measured: no change, 26.80 against 26.78 us)
+SHARE_SEARCH = int(os.environ.get('CITW_TEAM_SHARE_SEARCH', 1))    # 1: ... and the passes of round 1's index search with the helper waves SEARCH_WAVES (on the lightly loaded waves 1 and 3: four per team 26.8 -> 25.5 us; on waves 2 and 4, which also interpolate: 28.4)
+SHARE_1D = int(os.environ.get('CITW_TEAM_SHARE_1D', 1))            # 1: ... and the second pass of the 1-D interpolation (16 lanes per episode) runs on wave 3 beside wave 1's first
 SHARE_2D = int(os.environ.get('CITW_TEAM_SHARE_2D', 1))            # 1: with several episodes per team (lane groups) the passes of round 1's 2-D interpolation are shared with helper waves 2, 4, 6 (CITW_L2_SHARE)
 OFFLOAD_1D = int(os.environ.get('CITW_TEAM_OFFLOAD_1D', 1))          # 1: the 1-D interpolation pass of round 1 runs on helper wave 1 (after wave 0's index search, by flag) beside wave 0's 2-D pass
 SPREAD_MIN = float(os.environ.get('CITW_TEAM_SPREAD_MIN', 0))         # with SPREAD_INPUTS: only input cones at least this heavy (units) leave wave 0
@@ -150,7 +152,7 @@ class TeamGen(codegen.Gen):
         have = [set(A0w)] + [set() for _ in range(K - 1)]
         load = [sum(cost(m) for m in A0w) + fn_cost(A0w, 0, True) + LOOKUP_PHASES] + [0.0] * (K - 1)
         self.h1d = 1 if (OFFLOAD_1D and K > 2 and self.rounds[0]['L1']) else None
-        self.l2_helpers = [2, 4, 6] if (SHARE_2D and K >= 7 and self.h1d is not None and self.rounds[0]['L2']) else []
+        self.l2_helpers = L2_WAVES if (SHARE_2D and K >= 7 and self.h1d is not None and self.rounds[0]['L2']) else []
         if self.h1d is not None:
             load[self.h1d] += 220.0            # the 1-D pass it takes over from wave 0
             load[0] -= 220.0
@@ -481,9 +483,9 @@ class TeamGen(codegen.Gen):
                     B('  citw_iflag_raise(7, %s);   /* the look-up inputs are in g_in[0] */' % SEQ)
                     B('  citw_search_part<%d, %d, 0, CITW_SEARCH_SHARE(%d)>(wv, S[%d], lane);' % (R['maxn'], ns, ns, r))
                     B('  citw_iflag_raise(0, %s);' % SEQ)
-                    B('  citw_iflag_wait(2, %s);' % SEQ)
+                    B('  citw_iflag_wait(%d, %s);' % (SEARCH_WAVES[0], SEQ))
                     B('#if CITW_SEARCH_SHARE(%d) > 2' % ns)
-                    B('  citw_iflag_wait(4, %s);' % SEQ)
+                    B('  citw_iflag_wait(%d, %s);' % (SEARCH_WAVES[1], SEQ))
                     B('#endif')
                     B('#else')
                 B('  citw_search<%d, %d>(wv, S[%d], lane);' % (R['maxn'], len(R['searches']), r))
@@ -573,7 +575,7 @@ class TeamGen(codegen.Gen):
                 lookup_round(0, self.rounds[0], None)
                 done_rounds.add(0)
             def emit_search_share(bb):
-                kq = self.l2_helpers.index(bb) + 1
+                kq = SEARCH_WAVES.index(bb) + 1
                 nsq = len(self.rounds[0]['searches'])
                 B('#if CITW_SEARCH_SHARE(%d) > %d   /* several episodes per team: search pass %d, beside wave 0 */' % (nsq, kq, kq))
                 B('  citw_iflag_wait(7, %s);' % SEQ)
@@ -583,7 +585,7 @@ class TeamGen(codegen.Gen):
             B('  /* ---- share of this wave in the look-up independent glue */')
             foreign = lambda n: any(m in shared and self.row_slot[m][0] != b for m in self.closure([n], self.S0))
             order = sorted(self.pre_sinks[b], key=lambda n: (foreign(n), self.pre_sinks[b].index(n))) if shared else self.pre_sinks[b]
-            search_at = int(len(order) * SEARCH_AT) if (b in self.l2_helpers[:2] and SHARE_SEARCH and SEARCH_AT < 1.0) else -1
+            search_at = int(len(order) * SEARCH_AT) if (b in SEARCH_WAVES and self.l2_helpers and SHARE_SEARCH and SEARCH_AT < 1.0) else -1
             for kk, n in enumerate(order):
                 if kk == search_at:
                     emit_search_share(b)
@@ -613,18 +615,15 @@ class TeamGen(codegen.Gen):
                 """every wave that reads g_sidx waits for the waves that filled it"""
                 B('  citw_iflag_wait(0, %s);' % SEQ)
                 if self.l2_helpers and SHARE_SEARCH:
-                    if me != 2:
-                        B('#if CITW_SEARCH_SHARE(%d) > 1' % ns0)
-                        B('  citw_iflag_wait(2, %s);' % SEQ)
-                        B('#endif')
-                    if me != 4:
-                        B('#if CITW_SEARCH_SHARE(%d) > 2' % ns0)
-                        B('  citw_iflag_wait(4, %s);' % SEQ)
-                        B('#endif')
+                    for kq, wq in enumerate(SEARCH_WAVES[:2]):
+                        if me != wq:
+                            B('#if CITW_SEARCH_SHARE(%d) > %d' % (ns0, kq + 1))
+                            B('  citw_iflag_wait(%d, %s);' % (wq, SEQ))
+                            B('#endif')
+            if b in SEARCH_WAVES[:2] and self.l2_helpers and SHARE_SEARCH and SEARCH_AT >= 1.0:
+                emit_search_share(b)
             if b in self.l2_helpers:
                 k = self.l2_helpers.index(b) + 1
-                if SHARE_SEARCH and k <= 2 and SEARCH_AT >= 1.0:
-                    emit_search_share(b)
                 B('#if CITW_L2_SHARE > %d   /* several episodes per team: pass %d (of every CITW_L2_SHARE) of round 1\'s 2-D interpolation, beside wave 0 */' % (k, k))
                 wait_searches(b)
                 B('  citw_lookup2d_part<%d, %d, CITW_L2_SHARE>(0, L[0][0], g_out0, lane);' % (len(self.rounds[0]['L2']), k))
