@@ -65,10 +65,10 @@ static void serl_launch_rollout_teamg(int code, int groups, const RolloutArgs &a
 #undef SERL_TEAMG_CASE
 }
 
-// Episodes per team, 0 = use another kernel.  Measured per env step: 21.6 us with one episode per team, 23.5 with two,
-// 26.8 with four (the scalar glue is paid once for all lane groups; only the lane-parallel passes multiply, and the team's
+// Episodes per team, 0 = use another kernel.  Measured per env step: 21.6 us with one episode per team, 22.2 with two,
+// 25.6 with four (the scalar glue is paid once for all lane groups; only the lane-parallel passes multiply, and the team's
 // helpers share them), and one team fits a CU -- so up to 2 x CUs episodes run two per team and up to 4 x CUs four per team,
-// in ONE round of workgroups, against 57 us of the one-wavefront kernel (1 023 episodes: 37.4 M env-steps/s against 16).
+// in ONE round of workgroups, against 57 us of the one-wavefront kernel (1 023 episodes: 39.2 M env-steps/s against 16).
 // H = 32 only.  SERL_TEAM2=0 / 2 / 4 overrides (1 = 2).
 static int serl_use_teamg(const serl_ctx *c, const serl_rollout_desc *d, int episodes)
 {
