@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SERL_ABI_VERSION 5
+#define SERL_ABI_VERSION 6
 
 enum serl_error {
   SERL_OK = 0,
@@ -136,7 +136,11 @@ typedef struct serl_rollout_desc {
                                        streams (mixed-build sweeps: one call per dynamics build); the kernel and the
                                        wavefronts per workgroup are chosen for n_episodes + concurrent_episodes so that
                                        the launches fit the GPU side by side.  0 = this call has the GPU to itself */
-  int32_t pad_;
+  int32_t kernel_hint;              /* enum serl_kernel_hint: SERL_KERNEL_AUTO (0) = chosen from the episode count as
+                                       described at lanes_per_wave; the others force one of the wave-cooperative kernel
+                                       families (tests and A/B measurements compare them: results are bit-identical).
+                                       Ignored when lanes_per_wave > 0.  SERL_E_UNSUPPORTED when the forced kernel does not
+                                       exist for the actor shape (two / four episodes per team, half: hidden 32 only) */
   /* -- results (per episode) */
   double *fitness;                  /* sum of rewards incl. termination penalty */
   int32_t *length_steps;            /* number of env steps taken */
@@ -163,17 +167,31 @@ typedef struct serl_rollout_desc {
    *    action_dim must equal A.  reward = -sum_i<A |clip(scaler_i * error_i, -1, 1)| / A.  The per-episode tables keep
    *    their 3-column layouts (ref, err0, action_noise, actions: the first A columns are used / written, the others
    *    are 0); a transition row is (obs S, action A, next_obs S, reward, done, cost) = 2 S + A + 3 floats.
-   *    Configurations other than the default run on the one-wavefront-per-episode kernel. */
+   *    Configurations other than the default run on kernel instantiations of their own that read the widths from the
+   *    descriptor (serl_rollout_teamx_kernel_<variant>: rounds of one-episode teams while the episodes fit two rounds of
+   *    workgroups, i.e. <= 2 x CUs; serl_rollout_wavex_kernel_<variant>, one wavefront per episode, beyond). */
   int32_t env_config;
   int32_t incremental;
 } serl_rollout_desc;
 
 enum serl_env_config { SERL_ENV_ATTITUDE = 0, SERL_ENV_SYMMETRIC = 1, SERL_ENV_FULL = 2 };
+/* serl_rollout_desc.kernel_hint -- which wave-cooperative kernel family runs the episodes (all bit-identical):
+ *   TEAM   eight wavefronts = one episode (seven integrate, one runs the actor); rounds of CUs episodes
+ *   TEAM2 / TEAM4   the same team carrying two / four episodes in lane groups of 32 / 16 (hidden 32)
+ *   WAVE   one wavefront = one episode, up to four per workgroup
+ *   HALF   one wavefront = two episodes (hidden 32) */
+enum serl_kernel_hint { SERL_KERNEL_AUTO = 0, SERL_KERNEL_TEAM = 1, SERL_KERNEL_WAVE = 2, SERL_KERNEL_HALF = 3,
+                        SERL_KERNEL_TEAM2 = 4, SERL_KERNEL_TEAM4 = 5 };
 /* length of the observation of a configuration (0 = invalid) and its number of actions */
 int serl_env_state_dim(int env_config, int incremental);
 int serl_env_action_dim(int env_config);
 
 int serl_abi_version(void);
+/* Layout self-check for bindings that mirror the structs by hand (ctypes, cgo ...): fills out[0 .. n) with
+ *   sizeof(serl_rollout_desc), then offsetof of each of its members in declaration order,
+ *   then sizeof(serl_build_desc), sizeof(serl_fault_row), sizeof(serl_ref_spec), sizeof(serl_replay_job)
+ * as this library was compiled, and returns the number of values (written or not: call with capacity 0 to size). */
+int serl_abi_layout(int32_t *out, int32_t capacity);
 /* number of f32 parameters of an actor: H*S+H + L*(H*H+3H) + A*H+A */
 int serl_param_count(int state_dim, int hidden, int num_layers, int action_dim);
 const char *serl_last_error(void);
@@ -181,9 +199,10 @@ const char *serl_last_error(void);
 int serl_ctx_create(int device, serl_ctx **out);
 int serl_ctx_destroy(serl_ctx *ctx);
 int serl_ctx_load_build(serl_ctx *ctx, int slot, const serl_build_desc *build);
-/* The development switches (SERL_TEAM, SERL_WAVES_PER_BLOCK, SERL_HALF, SERL_PROFILE) are read from the environment once,
- * by serl_ctx_create; this re-reads them (A/B tests flip them between calls). */
-int serl_ctx_refresh_env(serl_ctx *ctx);
+/* Development overrides, read from the environment ONCE, by serl_ctx_create (the only getenv of the library):
+ *   SERL_KERNEL=team|team2|team4|wave|half   kernel family for descriptors with kernel_hint == SERL_KERNEL_AUTO
+ *   SERL_WAVES_PER_BLOCK=n                   wavefronts per workgroup of the one-wavefront kernels
+ *   SERL_PROFILE=1                           cycle counters for serl_debug_profile */
 
 /* One population evaluation: all episodes of the descriptor, one fused kernel launch per call. */
 int serl_rollout(serl_ctx *ctx, const serl_rollout_desc *desc, void *stream);
@@ -191,7 +210,7 @@ int serl_rollout(serl_ctx *ctx, const serl_rollout_desc *desc, void *stream);
 /* Dynamics only (test / micro-benchmark entry): per episode initialize() followed by T calls of the
  * reference's step(cmd) -- cmds f64 [n_episodes][T][10] -> states f64 [n_episodes][T][12] (device). */
 int serl_dyn_open_loop(serl_ctx *ctx, int slot, int32_t n_episodes, int32_t T, const double *cmds,
-                       double *states, int32_t lanes_per_wave, void *stream);
+                       double *states, int32_t lanes_per_wave, int32_t kernel_hint /* AUTO, TEAM or WAVE */, void *stream);
 
 /* Development aid: with SERL_PROFILE=1 in the environment serl_rollout records shader-clock cycles of wave 0 of
  * workgroup 0: out[0..3] = {actor forward, dynamics step, env bookkeeping, env steps}; out[4..31] = phase

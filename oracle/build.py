@@ -15,5 +15,12 @@ def build(force=False):
     return LIB
 
 
+def build_xcheck(force=False):
+    """GPU kernels around the lifted model (oracle/xcheck/): the checker's second implementation on the device."""
+    from oracle import xcheck
+    return xcheck.build(force)
+
+
 if __name__ == '__main__':
     print(build(force=True))
+    print(build_xcheck(force=True))

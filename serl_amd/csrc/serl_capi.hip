@@ -69,11 +69,13 @@ static void serl_launch_rollout_teamg(int code, int groups, const RolloutArgs &a
 // 25.6 with four (the scalar glue is paid once for all lane groups; only the lane-parallel passes multiply, and the team's
 // helpers share them), and one team fits a CU -- so up to 2 x CUs episodes run two per team and up to 4 x CUs four per team,
 // in ONE round of workgroups, against 57 us of the one-wavefront kernel (1 023 episodes: 39.2 M env-steps/s against 16).
-// H = 32 only.  SERL_TEAM2=0 / 2 / 4 overrides (1 = 2).
-static int serl_use_teamg(const serl_ctx *c, const serl_rollout_desc *d, int episodes)
+// H = 32 only.  kernel_hint SERL_KERNEL_TEAM2 / TEAM4 force it.
+static int serl_use_teamg(const serl_ctx *c, const serl_rollout_desc *d, int hint, int episodes)
 {
   if (d->hidden != 32) return 0;
-  if (c->env_team2 >= 0) return c->env_team2 == 0 ? 0 : (c->env_team2 == 4 ? 4 : 2);
+  if (hint == SERL_KERNEL_TEAM2) return 2;
+  if (hint == SERL_KERNEL_TEAM4) return 4;
+  if (hint != SERL_KERNEL_AUTO) return 0;
   if (episodes <= c->num_cus || episodes > 4 * c->num_cus) return 0;
   return episodes <= 2 * c->num_cus ? 2 : 4;
 }
@@ -81,31 +83,30 @@ static int serl_use_teamg(const serl_ctx *c, const serl_rollout_desc *d, int epi
 // Beyond 4 x CUs episodes the team kernels still win when the launch has the GPU to itself: 4 x CUs episodes per 30.8 us
 // is the rate of the two-episodes-per-wavefront kernel (8 x CUs per 62.9 us) at half the granularity, and the remainder runs
 // at the rate of its own size class.  Side-by-side launches (concurrent_episodes > 0) keep the half kernel: a team needs a
-// whole CU.  H = 32 only; SERL_TEAM2 / SERL_HALF overrides switch it off.
-static bool serl_use_team_rounds(const serl_ctx *c, const serl_rollout_desc *d, int episodes)
+// whole CU.  H = 32 only; any kernel_hint other than AUTO switches it off.
+static bool serl_use_team_rounds(const serl_ctx *c, const serl_rollout_desc *d, int hint, int episodes)
 {
-  if (d->hidden != 32 || c->env_team2 >= 0 || c->env_half >= 0 || c->env_team == 0) return false;
+  if (d->hidden != 32 || hint != SERL_KERNEL_AUTO) return false;
   return d->concurrent_episodes <= 0 && episodes > 4 * c->num_cus;
 }
 
 // The one-wavefront-per-episode kernel runs up to 4 x CUs episodes at once (one per SIMD); beyond that the launch needs a
 // second round of wavefronts, and packing two episodes into a wavefront (1.1 x the time per env step) is the better deal.
-// H = 32 only (the lane group of an episode holds one hidden row per lane).  SERL_HALF=0 / 1 overrides.
-static bool serl_use_half(const serl_ctx *c, const serl_rollout_desc *d, int episodes)
+// H = 32 only (the lane group of an episode holds one hidden row per lane).  kernel_hint SERL_KERNEL_HALF forces it.
+static bool serl_use_half(const serl_ctx *c, const serl_rollout_desc *d, int hint, int episodes)
 {
   if (d->hidden != 32) return false;
-  if (c->env_half >= 0) return c->env_half != 0;
+  if (hint != SERL_KERNEL_AUTO) return hint == SERL_KERNEL_HALF;
   return episodes > 4 * c->num_cus;
 }
 
 // One episode per workgroup and one workgroup per CU (the LDS copy of the tables): a team finishes an env step in
 // ~0.37 of the time a lone wavefront needs (21.2 vs 57 us), but only one team fits a CU where four lone wavefronts
 // would: teams while every episode gets a CU of its own (measured: 320 episodes as teams 88 us, 400 alone 59 us),
-// lone wavefronts beyond.  SERL_TEAM=0 / 1 overrides.
-static bool serl_use_team(const serl_ctx *c, int code, int episodes)
+// lone wavefronts beyond.  kernel_hint SERL_KERNEL_TEAM forces it (any other hint excludes it).
+static bool serl_use_team(const serl_ctx *c, int hint, int episodes)
 {
-  (void)code;
-  if (c->env_team >= 0) return c->env_team != 0;
+  if (hint != SERL_KERNEL_AUTO) return hint == SERL_KERNEL_TEAM;
   return episodes <= c->num_cus;
 }
 
@@ -212,27 +213,31 @@ static int serl_waves_per_block(const serl_ctx *c, int waves)
   return waves <= c->num_cus ? 1 : 4;
 }
 
-// development / A-B switches: read when the context is created and by serl_ctx_refresh_env (tests flip them between calls)
-static void serl_ctx_read_env(serl_ctx *c)
-{
-  const char *e;
-  c->env_team = (e = getenv("SERL_TEAM")) ? atoi(e) : -1;
-  c->env_waves_per_block = (e = getenv("SERL_WAVES_PER_BLOCK")) ? atoi(e) : -1;
-  c->env_half = (e = getenv("SERL_HALF")) ? atoi(e) : -1;
-  c->env_team2 = (e = getenv("SERL_TEAM2")) ? atoi(e) : -1;
-  c->env_profile = getenv("SERL_PROFILE") != nullptr;
-}
+// descriptor hint first, then the context's development override (SERL_KERNEL, read once by serl_ctx_create)
+static int serl_resolve_hint(const serl_ctx *c, int desc_hint) { return desc_hint != SERL_KERNEL_AUTO ? desc_hint : c->env_kernel; }
 
 extern "C" {
 
-int serl_ctx_refresh_env(serl_ctx *c)
-{
-  if (!c) return fail(SERL_E_INVALID, "serl_ctx_refresh_env: NULL context");
-  serl_ctx_read_env(c);
-  return SERL_OK;
-}
-
 int serl_abi_version(void) { return SERL_ABI_VERSION; }
+
+int serl_abi_layout(int32_t *out, int32_t capacity)
+{
+#define SERL_OFF(m) (int32_t)offsetof(serl_rollout_desc, m)
+  const int32_t v[] = {
+    (int32_t)sizeof(serl_rollout_desc),
+    SERL_OFF(state_dim), SERL_OFF(action_dim), SERL_OFF(hidden), SERL_OFF(num_layers), SERL_OFF(activation), SERL_OFF(n_members),
+    SERL_OFF(weights), SERL_OFF(weight_stride), SERL_OFF(n_episodes), SERL_OFF(build_slot), SERL_OFF(member_of_episode),
+    SERL_OFF(faults), SERL_OFF(ref), SERL_OFF(ref_stride), SERL_OFF(err0), SERL_OFF(action_noise), SERL_OFF(noise_row),
+    SERL_OFF(sensor_noise), SERL_OFF(sensor_row), SERL_OFF(tick0), SERL_OFF(t_max), SERL_OFF(max_steps), SERL_OFF(lanes_per_wave),
+    SERL_OFF(concurrent_episodes), SERL_OFF(kernel_hint), SERL_OFF(fitness), SERL_OFF(length_steps), SERL_OFF(length_t),
+    SERL_OFF(cost_steps), SERL_OFF(actions), SERL_OFF(states), SERL_OFF(rewards), SERL_OFF(transitions), SERL_OFF(ref_spec),
+    SERL_OFF(ref_spec_stride), SERL_OFF(env_config), SERL_OFF(incremental),
+    (int32_t)sizeof(serl_build_desc), (int32_t)sizeof(serl_fault_row), (int32_t)sizeof(serl_ref_spec), (int32_t)sizeof(serl_replay_job)};
+#undef SERL_OFF
+  const int32_t n = (int32_t)(sizeof(v) / sizeof(v[0]));
+  for (int32_t i = 0; out && i < n && i < capacity; ++i) out[i] = v[i];
+  return n;
+}
 
 // envs/phlabenv.py:84-97 (obs_idx per configuration), :213-220 (n_obs)
 int serl_env_action_dim(int env_config) { return env_config == SERL_ENV_SYMMETRIC ? 1 : 3; }
@@ -262,7 +267,17 @@ int serl_ctx_create(int device, serl_ctx **out)
       if (prop.sharedMemPerBlockOptin > 0) c->lds_per_block = (int)prop.sharedMemPerBlockOptin;
     }
   }
-  serl_ctx_read_env(c);
+  {   // development overrides: the library's only look at the process environment
+    const char *e;
+    c->env_kernel = SERL_KERNEL_AUTO;
+    if ((e = getenv("SERL_KERNEL")) != nullptr) {
+      const std::string k(e);
+      c->env_kernel = k == "team" ? SERL_KERNEL_TEAM : k == "team2" ? SERL_KERNEL_TEAM2 : k == "team4" ? SERL_KERNEL_TEAM4
+                    : k == "wave" ? SERL_KERNEL_WAVE : k == "half" ? SERL_KERNEL_HALF : SERL_KERNEL_AUTO;
+    }
+    c->env_waves_per_block = (e = getenv("SERL_WAVES_PER_BLOCK")) ? atoi(e) : -1;
+    c->env_profile = getenv("SERL_PROFILE") != nullptr;
+  }
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   *out = c;
@@ -327,6 +342,10 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   if (d->weight_stride < serl_param_count(d->state_dim, d->hidden, d->num_layers, d->action_dim))
     return fail(SERL_E_INVALID, "serl_rollout: weight_stride smaller than the parameter count");
   if (d->max_steps <= 0) return fail(SERL_E_INVALID, "serl_rollout: max_steps");
+  if (d->kernel_hint < SERL_KERNEL_AUTO || d->kernel_hint > SERL_KERNEL_TEAM4) return fail(SERL_E_INVALID, "serl_rollout: kernel_hint");
+  const int hint = d->lanes_per_wave > 0 ? SERL_KERNEL_AUTO : serl_resolve_hint(c, d->kernel_hint);
+  if (d->hidden != 32 && (hint == SERL_KERNEL_TEAM2 || hint == SERL_KERNEL_TEAM4 || hint == SERL_KERNEL_HALF))
+    return fail(SERL_E_UNSUPPORTED, "serl_rollout: the multi-episode kernels (kernel_hint TEAM2 / TEAM4 / HALF) exist for hidden = 32 only");
   HIP_TRY(hipSetDevice(c->device));
   const BuildSlot &s = c->slots[d->build_slot];
   hipStream_t stream = (hipStream_t)stream_;
@@ -351,7 +370,9 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     // observation set / number of actions / incremental control from the descriptor: the team kernel while the episodes fit two
     // rounds of workgroups (2 x ~23 us per env step against 57 of one wavefront per episode), one wavefront per episode beyond
     if (!serl_has_wave_kernel(s.code)) return fail(SERL_E_UNSUPPORTED, "serl_rollout: code variant without a wave kernel");
-    const bool team = c->env_team >= 0 ? c->env_team != 0 : (d->concurrent_episodes <= 0 ? together <= 2 * c->num_cus : together <= c->num_cus);
+    if (hint != SERL_KERNEL_AUTO && hint != SERL_KERNEL_TEAM && hint != SERL_KERNEL_WAVE)
+      return fail(SERL_E_UNSUPPORTED, "serl_rollout: env configurations other than the attitude task run on the TEAM or WAVE kernels");
+    const bool team = hint != SERL_KERNEL_AUTO ? hint == SERL_KERNEL_TEAM : (d->concurrent_episodes <= 0 ? together <= 2 * c->num_cus : together <= c->num_cus);
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
     if (team) {
       a.lanes = 1;
@@ -373,7 +394,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     c->timed = timed;
     return SERL_OK;
   }
-  if (lanes <= 0 && serl_use_team(c, s.code, together)) {
+  if (lanes <= 0 && serl_use_team(c, hint, together)) {
     a.lanes = 1;
     a.block = 128;
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
@@ -383,7 +404,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     c->timed = timed;
     return SERL_OK;
   }
-  const int teamg = (lanes <= 0 && serl_has_wave_kernel(s.code) && !(c->env_half > 0)) ? serl_use_teamg(c, d, together) : 0;
+  const int teamg = (lanes <= 0 && serl_has_wave_kernel(s.code)) ? serl_use_teamg(c, d, hint, together) : 0;
   if (teamg) {
     a.lanes = 1;
     a.block = 512;
@@ -394,7 +415,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     c->timed = timed;
     return SERL_OK;
   }
-  if (lanes <= 0 && serl_has_wave_kernel(s.code) && serl_use_team_rounds(c, d, together)) {
+  if (lanes <= 0 && serl_has_wave_kernel(s.code) && serl_use_team_rounds(c, d, hint, together)) {
     // more than 4 x CUs episodes, alone on the GPU: rounds of 4 x CUs episodes (four per team, every CU busy), then the rest
     // with whichever team kernel suits its count -- 4 x CUs + 2 episodes cost 30.8 + 21.6 us per env step, not 62.9
     a.lanes = 1;
@@ -415,7 +436,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     c->timed = timed;
     return SERL_OK;
   }
-  if (lanes <= 0 && serl_has_wave_kernel(s.code) && serl_use_half(c, d, together)) {
+  if (lanes <= 0 && serl_has_wave_kernel(s.code) && serl_use_half(c, d, hint, together)) {
     const int waves = (d->n_episodes + 1) / 2;
     int wpb = (waves + c->num_cus - 1) / c->num_cus;
     wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
@@ -468,9 +489,12 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
 }
 
 int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, const double *cmds, double *states,
-                       int32_t lanes_per_wave, void *stream_)
+                       int32_t lanes_per_wave, int32_t kernel_hint, void *stream_)
 {
   if (!c || !cmds || !states || n_episodes <= 0 || T <= 0) return fail(SERL_E_INVALID, "serl_dyn_open_loop: bad argument");
+  const int hint = lanes_per_wave > 0 ? SERL_KERNEL_AUTO : serl_resolve_hint(c, kernel_hint);
+  if (hint != SERL_KERNEL_AUTO && hint != SERL_KERNEL_TEAM && hint != SERL_KERNEL_WAVE)
+    return fail(SERL_E_UNSUPPORTED, "serl_dyn_open_loop: kernel_hint must be AUTO, TEAM or WAVE");
   if (slot < 0 || slot >= SERL_MAX_SLOTS || !c->slots[slot].loaded) return fail(SERL_E_INVALID, "serl_dyn_open_loop: build slot not loaded");
   HIP_TRY(hipSetDevice(c->device));
   const BuildSlot &s = c->slots[slot];
@@ -480,7 +504,7 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
   a.ro = s.blob; a.t3 = s.blob + s.n_ro; a.x0 = a.t3 + 46; a.dw0 = a.x0 + 19;
   a.dyn_dt = s.dt;
   hipStream_t stream = (hipStream_t)stream_;
-  if (lanes_per_wave <= 0 && serl_use_team(c, s.code, n_episodes)) {
+  if (lanes_per_wave <= 0 && serl_use_team(c, hint, n_episodes)) {
     a.lanes = 1;
     a.block = 128;
     HIP_TRY(hipEventRecord(c->ev0, stream));

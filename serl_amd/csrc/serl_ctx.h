@@ -29,7 +29,7 @@ struct serl_ctx {
   int num_cus = 256;                    // multiProcessorCount of this context's device
   int lds_per_block = 65536;            // sharedMemPerBlockOptin
   // environment overrides, read once when the context is made (-1 = not set)
-  int env_team = -1, env_waves_per_block = -1, env_profile = 0, env_half = -1, env_team2 = -1;
+  int env_kernel = 0 /* serl_kernel_hint from SERL_KERNEL */, env_waves_per_block = -1, env_profile = 0;
   BuildSlot slots[SERL_MAX_SLOTS];
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;

@@ -40,16 +40,6 @@ class PopResult:
     episode_member: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
 
 
-_engines = None
-
-
-def refresh_env():
-    """Development switches (SERL_TEAM, SERL_WAVES_PER_BLOCK, SERL_PROFILE ...) are read once per context; A/B tests that
-    flip them between calls re-read them through this."""
-    for e in list(_engines or ()):
-        e.refresh_env()
-
-
 class RolloutEngine:
     """One per process / GPU.  Not thread-safe (one HIP context, calls are stream-ordered)."""
 
@@ -67,15 +57,9 @@ class RolloutEngine:
         # queues when it is created, and streams made back to back land on different ones (measured: profiles/r01_g_mixed.md)
         self._side = [torch.cuda.Stream(self.device) for _ in range(3)]
         self.last_kernel_ms = 0.0
-        global _engines
-        if _engines is None:
-            import weakref
-            _engines = weakref.WeakSet()
-        _engines.add(self)
-
-    def refresh_env(self):
-        if getattr(self, 'ctx', None):
-            _capi.check(self.lib.serl_ctx_refresh_env(self.ctx), 'serl_ctx_refresh_env')
+        # serl_rollout_desc.kernel_hint of rollouts that do not name one (None = chosen from the episode count); tests and
+        # A/B measurements set it to compare the kernel families ('team', 'team2', 'team4', 'wave', 'half')
+        self.kernel_hint = None
 
     def close(self):
         if getattr(self, 'ctx', None):
@@ -111,7 +95,7 @@ class RolloutEngine:
     # ------------------------------------------------------------------------------------------
     def rollout(self, weights, spec: NetSpec, member_of_episode, ref, *, build='h2000_v90', faults=None,
                 err0=None, tick0=None, action_noise=None, noise_row=None, sensor_noise=None, sensor_row=None, t_max=80.0, traces=False,
-                transitions=False, lanes_per_wave=0, sync=True, concurrent_episodes=0, env_config=0, incremental=False):
+                transitions=False, lanes_per_wave=0, sync=True, concurrent_episodes=0, env_config=0, incremental=False, kernel=None):
         """Low-level: run len(member_of_episode) episodes.  weights f32 [M, >=P] (device or host),
         ref f64 [E, T, 3] or [T, 3] radians.  env_config / incremental: builds.env_config(name) (the attitude task by
         default; the per-episode tables keep their 3-column layouts, transitions have 2 S + A + 3 columns).
@@ -146,6 +130,7 @@ class RolloutEngine:
                               build_slot=self.slot_of(build), member_of_episode=moe.data_ptr(),
                               ref=0 if ref_t is None else ref_t.data_ptr(), ref_stride=0 if shared else T * 3, t_max=float(t_max),
                               max_steps=T, lanes_per_wave=int(lanes_per_wave),
+                              kernel_hint=_capi.KERNEL_HINTS[kernel if kernel is not None else self.kernel_hint],
                               concurrent_episodes=int(concurrent_episodes), env_config=int(env_config), incremental=int(bool(incremental)),
                               fitness=out['fitness'].data_ptr(), length_steps=out['length_steps'].data_ptr(),
                               length_t=out['length_t'].data_ptr(), cost_steps=out['cost_steps'].data_ptr())
@@ -203,7 +188,7 @@ class RolloutEngine:
                                    % (int(bad.sum()), T))
         return out
 
-    def dynamics_open_loop(self, cmds, build='h2000_v90', lanes_per_wave=0):
+    def dynamics_open_loop(self, cmds, build='h2000_v90', lanes_per_wave=0, kernel=None):
         """Dynamics only: cmds f64 [E, T, 10] -> states f64 [E, T, 12] (what the reference's raw
         initialize()/step() return for the same command sequence)."""
         c = torch.as_tensor(cmds, dtype=torch.float64).to(self.device).contiguous()
@@ -211,7 +196,8 @@ class RolloutEngine:
         out = torch.zeros(E, T, 12, dtype=torch.float64, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _capi.check(self.lib.serl_dyn_open_loop(self.ctx, self.slot_of(build), E, T, c.data_ptr(), out.data_ptr(),
-                                                int(lanes_per_wave), ctypes.c_void_p(stream)), 'serl_dyn_open_loop')
+                                                int(lanes_per_wave), _capi.KERNEL_HINTS[kernel if kernel is not None else self.kernel_hint],
+                                                ctypes.c_void_p(stream)), 'serl_dyn_open_loop')
         self.kernel_ms()
         return out
 

@@ -34,7 +34,9 @@ def engine():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     import serl_amd
-    return serl_amd.RolloutEngine(0)
+    from serl_amd import evaluator
+    evaluator._default_engine = eng = serl_amd.RolloutEngine(0)       # one context: `kernel(...)` blocks of the tests set its kernel_hint
+    return eng
 
 
 RTOL = 1e-5          # BASELINE.json north_star: episodic return within 1e-5 relative
@@ -103,7 +105,7 @@ class OracleEngine:
 
     def rollout(self, weights, spec, member_of_episode, ref, *, build='h2000_v90', faults=None, err0=None, tick0=None,
                 action_noise=None, noise_row=None, sensor_noise=None, sensor_row=None, t_max=80.0, traces=False,
-                transitions=False, lanes_per_wave=0, sync=True, concurrent_episodes=0, env_config=0, incremental=False):
+                transitions=False, lanes_per_wave=0, sync=True, concurrent_episodes=0, env_config=0, incremental=False, kernel=None):
         import numpy as np, torch
         from oracle import rollout as R
         net = dict(state_dim=spec.state_dim, action_dim=spec.action_dim, hidden=spec.hidden, num_layers=spec.num_layers,

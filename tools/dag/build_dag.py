@@ -22,7 +22,7 @@ def ro_constants(variant):
 
 
 def build(variant, fast_zero=False, fold_ro=True):
-    text = open(os.path.join(ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s.inc' % variant)).read()
+    text = open(os.path.join(ROOT, 'oracle', 'gen', 'citation_%s.inc' % variant)).read()
     roc, datas = ro_constants(variant)
     g = symex.Dag()
     res = {}

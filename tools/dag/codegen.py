@@ -43,7 +43,7 @@ class Gen:
         self.lds_consts = lds_consts
         self.kslot = {}
         self.g, self.res, self.datas = build_dag.build(variant, fast_zero=fast_zero)
-        inc = open(os.path.join(build_dag.ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s.inc' % variant)).read()
+        inc = open(os.path.join(build_dag.ROOT, 'oracle', 'gen', 'citation_%s.inc' % variant)).read()
         import re
         self.ro_base = int(re.search(r'#define RO_BASE (0x[0-9a-f]+)', inc).group(1), 16)
         self.ro_lo = int(re.search(r'#define RO_USED_LO (0x[0-9a-f]+)', inc).group(1), 16)

@@ -295,7 +295,7 @@ def main():
     ap.add_argument('builds', nargs='*')
     a = ap.parse_args()
     root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    outdirs = [os.path.join(root, 'oracle', 'gen'), os.path.join(root, 'serl_amd', 'csrc', 'gen')]
+    outdirs = [os.path.join(root, 'oracle', 'gen')]      # the lifted source is the checker's; the product ships what tools/dag generates from it
     datadir = os.path.join(root, 'serl_amd', 'data')
     for d in outdirs + [datadir]:
         os.makedirs(d, exist_ok=True)
