@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the population-rollout fitness evaluation (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload serl50|serl10|mixed] [--pop MEMBERS_PER_GPU]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload serl50|serl10|mixed] [--pop MEMBERS_PER_GPU | --total-pop MEMBERS]
   (N > 1: one rank per GPU over RCCL -- launched by torch.distributed.run, or, when started as a plain
    `python bench.py --gpus N`, bench.py re-executes itself under torch.distributed.run; fewer than N visible GPUs ->
    one JSON line {"skipped": ...} and exit code 0)
 
 A "step" is one population evaluation: pop members x num_evals episodes x 8 001 env steps of the
 PH-LAB attitude-tracking task (t_max = 80 s), weights and reference tables already resident in HBM.
-Weak scaling: every GPU evaluates its own block of `pop` members (shipped actors, tiled with seeded noise
+Default (weak scaling): every GPU evaluates its own block of `pop` members (shipped actors, tiled with seeded noise
 beyond the shipped ones) and the per-member result rows are all-gathered (RCCL).  Prints ONE JSON line on rank 0.
+--total-pop M (strong scaling, BASELINE configs 4 / 5): ONE population of M members sharded over the N ranks in contiguous
+member blocks (serl_amd.distributed.member_block, the partition of base/core/agent.py:234-256's loop), "scaling": "strong";
+with --gpus 1 all M x num_evals episodes run on one GPU and are checked against the CPU restatement.
 
 Workloads (BASELINE.json configs): serl50 = config 3 (the metric's configuration, default: pop=50, actor 7-32x4-3;
 --pop 64 is one GPU's share of config 4, pop=512 over 8), serl10 = config 2 (pop=10, actor 7-72x4-3), mixed = one
@@ -69,29 +72,32 @@ def cpu_port(w, hidden, ref, moe, faults_of=None, build_of=None):
 
 
 def cpu_baseline(w, hidden, ref, moe, faults_of=None, build_of=None):
-    """the reference's own Python path, one process per host core, where /root/reference exists (build
-    container); the GPU box has no reference tree, so there the C restatement is what can be timed in-run
-    (kind = "port") and the committed build-container measurement of the reference Python travels beside it."""
-    cb, fit, ls = cpu_port(w, hidden, ref, moe, faults_of, build_of)
-    try:
-        committed = json.load(open(os.path.join(ROOT, 'profiles', 'r02_reference_cpu.json')))
-    except Exception:
-        committed = None
-    if os.path.isdir(os.path.join(REFERENCE, 'envs', 'h2000_v90')):
-        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'tools', 'time_reference.py'), '--episodes', '1'],
-                           capture_output=True, text=True, timeout=600)
-        m = json.loads(r.stdout.strip().splitlines()[-1])
-        cb = dict(value=m['env_steps_per_s'], unit='env-steps/s', cores=m['procs'], kind='reference-python',
-                  sample='%d processes x %d full 80 s episodes (after one warm-up each) of the reference\'s unmodified Agent.evaluate, '
-                         '%.1f s wall' % (m['procs'], m['episodes_per_proc'], m['seconds']), port=cb)
-    elif committed is not None:
-        cb['reference_python_build_container'] = {
-            'value': committed['env_steps_per_s'], 'unit': 'env-steps/s', 'cores': committed['procs'],
-            'per_core': committed['env_steps_per_s_per_core'], 'source': 'profiles/r02_reference_cpu.json',
-            'note': 'the reference\'s unmodified Python (Agent.evaluate + CitationEnv + torch Actor + its _citation library), one '
-                    'process per core, timed in the build container (tests/tools/time_reference.py); /root/reference does not '
-                    'exist on the GPU box, so it cannot be re-timed in this run'}
-    return cb, fit, ls
+    """the reference's OWN Python path (unmodified Agent.evaluate + CitationEnv + torch Actor + its prebuilt
+    dynamics library), one process per host core of THIS box, timed in THIS run (tests/tools/time_reference.py): from
+    /root/reference in the build container, from the archive oracle/build.py stage_ref() packs into the git-ignored
+    oracle/_ref/ on the GPU box.  The C restatement (oracle/rollout_ref.c) on all host threads rides along as `port` (it is
+    also the checker of parity_vs_cpu_port)."""
+    # a bounded sample for the C restatement: at most 1 536 episodes (~18 s on 256 threads)
+    n = min(len(moe), 1536)
+    port, fit, ls = cpu_port(w, hidden, ref[:n], moe[:n], None if faults_of is None else faults_of[:n], None if build_of is None else build_of[:n])
+    from oracle import refso
+    cb = None
+    if refso.available():
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'tools', 'time_reference.py'), '--episodes', '1'],
+                               capture_output=True, text=True, timeout=900)
+            m = json.loads(r.stdout.strip().splitlines()[-1])
+            cb = dict(value=m['env_steps_per_s'], unit='env-steps/s', cores=m['procs'], kind='reference-python',
+                      per_core=m['env_steps_per_s_per_core'], reference=m['reference'],
+                      sample='%d processes (one per host core) x %d full 80 s episode(s) = %d env steps of the reference\'s unmodified '
+                             'Agent.evaluate (SERL50 actors, base reference, nominal build) after a 5 s warm-up episode each, %.1f s wall '
+                             '(+ %.0f s process start-up, untimed)' % (m['procs'], m['episodes_per_proc'], m['env_steps'], m['seconds'], m['startup_seconds']),
+                      port=port)
+        except Exception as ex:          # the reference leg must never take the bench line down
+            port['reference_python_error'] = repr(ex)[:300]
+    if cb is None:
+        cb = port
+    return cb, fit, ls, n
 
 
 def self_launch(a):
@@ -118,6 +124,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='serl50')
     ap.add_argument('--pop', type=int, default=0, help='members per GPU (0 = the workload\'s own)')
+    ap.add_argument('--total-pop', type=int, default=0, help='strong scaling: ONE population of this many members sharded over the ranks')
     ap.add_argument('--num-evals', type=int, default=3)
     ap.add_argument('--lanes', type=int, default=0, help='episodes per wavefront (0 = auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -142,17 +149,29 @@ def main():
 
     wl = WORKLOADS[a.workload]
     spec = serl_amd.NetSpec(7, 3, wl['hidden'], 3, 'tanh')
-    pop, ne = a.pop or wl['pop'], a.num_evals
+    ne = a.num_evals
+    strong = a.total_pop > 0
+    if strong:
+        # ONE population, contiguous member blocks (the reference's `for net in pop` loop, base/core/agent.py:234-256, cut into
+        # `world` pieces); every rank builds only its own block of the deterministic population / references
+        lo, hi = sd.member_block(a.total_pop, world, rank)
+        pop = hi - lo
+        w_host = make_population(a.total_pop, 0, tag=wl['tag'])[lo:hi].contiguous()
+        ref_host = refsignals.synthetic_reference_tables(pop * ne, ne, 80, seed=7, first=lo * ne)
+        gather_pop = a.total_pop
+    else:
+        lo, pop = 0, a.pop or wl['pop']
+        w_host = make_population(pop, rank, tag=wl['tag'])
+        ref_host = refsignals.synthetic_reference_tables(pop * ne, ne, 80, seed=7 + 100000 * rank)
+        gather_pop = pop * world
     E = pop * ne
-    w_host = make_population(pop, rank, tag=wl['tag'])
-    ref_host = refsignals.synthetic_reference_tables(E, ne, 80, seed=7 + 100000 * rank)
     eng = serl_amd.RolloutEngine(local)
     w = w_host.to(dev)
     ref = torch.from_numpy(ref_host).to(dev)
     moe = np.repeat(np.arange(pop, dtype=np.int32), ne)
     T = ref.shape[1]
     mixed = a.workload == 'mixed'
-    modes = [MIXED_MODES[e % 6] for e in range(E)] if mixed else None
+    modes = [MIXED_MODES[(lo * ne + e) % 6] for e in range(E)] if mixed else None
 
     def evaluate(wd, refd, moe_, n_members, modes_=None):
         """one population evaluation on this rank -> (rows f64 [ne, members, ROW] on the device, length_steps, fitness)"""
@@ -172,7 +191,7 @@ def main():
     def one_step():
         """one population evaluation on this rank + the fitness all-gather + index selection"""
         rows, ls, fit = evaluate(w, ref, moe, pop, modes)
-        g = sd.gather_rows(rows, pop * world, world, rank, device=dev)
+        g = sd.gather_rows(rows, gather_pop, world, rank, device=dev)
         pop_fitness = g[..., 0].mean(0)
         champion = int(torch.argmax(pop_fitness))
         return ls, fit, g, champion
@@ -208,11 +227,16 @@ def main():
     if world > 1 and not a.no_partition_check:
         # the gathered result of the N-way sharded evaluation must be bit-identical to ONE GPU
         # evaluating the same pop x world members (rank 0 rebuilds every rank's block: the inputs are deterministic)
-        ws = torch.cat([make_population(pop, r, tag=wl['tag']) for r in range(world)]).to(dev)
-        rs = torch.cat([torch.from_numpy(refsignals.synthetic_reference_tables(E, ne, 80, seed=7 + 100000 * r)) for r in range(world)]).to(dev)
-        rows1, _, _ = evaluate(ws, rs, np.repeat(np.arange(pop * world, dtype=np.int32), ne), pop * world,
-                               None if not mixed else [MIXED_MODES[(e % E) % 6] for e in range(E * world)])
-        res_extra['partition_invariance'] = {'members': pop * world, 'bit_identical_to_one_gpu': bool(torch.equal(rows1, g)),
+        if strong:
+            ws = make_population(gather_pop, 0, tag=wl['tag']).to(dev)
+            rs = torch.from_numpy(refsignals.synthetic_reference_tables(gather_pop * ne, ne, 80, seed=7)).to(dev)
+            ms = [MIXED_MODES[e % 6] for e in range(gather_pop * ne)]
+        else:
+            ws = torch.cat([make_population(pop, r, tag=wl['tag']) for r in range(world)]).to(dev)
+            rs = torch.cat([torch.from_numpy(refsignals.synthetic_reference_tables(E, ne, 80, seed=7 + 100000 * r)) for r in range(world)]).to(dev)
+            ms = [MIXED_MODES[(e % E) % 6] for e in range(E * world)]
+        rows1, _, _ = evaluate(ws, rs, np.repeat(np.arange(gather_pop, dtype=np.int32), ne), gather_pop, ms if mixed else None)
+        res_extra['partition_invariance'] = {'members': gather_pop, 'bit_identical_to_one_gpu': bool(torch.equal(rows1, g)),
                                              'champion': champion}
     # informational (never `value`): the same evaluation when the boundary hands over HOST buffers -- weights and
     # reference tables cross PCIe inside the timed region (pinned memory, one H2D copy each per evaluation)
@@ -230,23 +254,39 @@ def main():
     # HBM traffic of one launch and the issue-slot occupancy from the PMC passes committed under profiles/ (rocprofv3 --pmc,
     # collected and corrected as MI355X_MICROARCH.md prescribes); only quoted for the configuration they were measured on
     traffic, issue = None, None
+    t_step_us = k_ms * 1e3 / T                   # per env step and team: measured in THIS run (HIP events around the kernel)
     try:
+        # the floors are properties of the model DAG (tools/dag/critical_path.py, committed with the generated kernels); the
+        # fraction printed is floor / THIS run's measured time per env step
+        fl = json.load(open(os.path.join(ROOT, 'profiles', 'floors_current.json')))
+        issue = {'bound': 'valu issue slots (wave-uniform f64 glue: 63 of 64 lanes of every instruction carry the same scalar)',
+                 'issue_floor_us_per_env_step': fl['issue_floor_us_per_env_step'],
+                 'dependency_floor_us_per_env_step': fl['dependency_floor_us_per_env_step'],
+                 'measured_us_per_env_step': t_step_us,
+                 'issue_floor_frac': fl['issue_floor_us_per_env_step'] / t_step_us if (not mixed and E <= 256) else None,
+                 'frac_note': 'issue floor (minimal instruction count of the model DAG x 4 cycles over the 4 SIMDs of a CU, '
+                              'tools/dag/critical_path.py) / measured time per env step of one team; defined for one episode per '
+                              'team (episodes <= CUs)'}
         pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_current.json')))
-        if pm.get('workload') == a.workload and pm.get('pop') == pop and ne == 3 and a.lanes == 0:
-            traffic, issue = pm.get('traffic_bytes_per_launch'), pm.get('issue')
+        if pm.get('workload') == a.workload and pm.get('pop') == pop and ne == 3 and a.lanes == 0 and not strong:
+            traffic = pm.get('traffic_bytes_per_launch')
+            issue['sq_counters'] = dict({k: pm['issue'][k] for k in ('active_frac', 'wait_frac', 'issue_stall_frac', 'simd_issue_frac',
+                                                                    'valu_per_env_step', 'salu_per_env_step', 'lds_per_env_step') if k in pm.get('issue', {})},
+                                        source='committed profile (profiles/pmc_current.json: rocprofv3 --pmc passes of an earlier run of this command), not measured in this run')
     except Exception:
         pass
     name = {'serl50': 'PH-LAB nominal h2000_v90, pop=%d (SERL50 actor 7-32x4-3 tanh)',
             'serl10': 'PH-LAB nominal h2000_v90, pop=%d (SERL10 actor 7-72x4-3 tanh)',
-            'mixed': 'PH-LAB mixed-fault sweep (be/jr/sa/se/ice/cg by episode), pop=%d (SERL50 actor shape)'}[a.workload] % pop
+            'mixed': 'PH-LAB mixed-fault sweep (be/jr/sa/se/ice/cg by episode), pop=%d (SERL50 actor shape)'}[a.workload] % (gather_pop if strong else pop)
     res = {
-        'metric': 'env-steps/sec (whole node), pop-rollout eval, pop=%d %s per GPU' % (pop, 'mixed-fault' if mixed else 'nominal'),
+        'metric': ('env-steps/sec (whole node), pop-rollout eval, pop=%d %s sharded over the GPUs' % (a.total_pop, 'mixed-fault' if mixed else 'nominal')) if strong
+                  else 'env-steps/sec (whole node), pop-rollout eval, pop=%d %s per GPU' % (pop, 'mixed-fault' if mixed else 'nominal'),
         'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-        'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
         'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': '%s x num_evals=%d x 8001 steps (t_max=80 s) per GPU; shipped weights (tiled+noise beyond the '
-                               'shipped ones), seeded smoothed-step references' % (name, ne),
-                   'pop_per_gpu': pop, 'num_evals': ne, 'episodes_per_gpu': E, 'steps_per_episode': T,
+        'config': {'workload': '%s x num_evals=%d x 8001 steps (t_max=80 s) %s; shipped weights (tiled+noise beyond the '
+                               'shipped ones), seeded smoothed-step references' % (name, ne, 'in all, sharded by member' if strong else 'per GPU'),
+                   'pop_per_gpu': pop, 'total_pop': gather_pop, 'num_evals': ne, 'episodes_per_gpu': E, 'steps_per_episode': T,
                    'lanes_per_wave': a.lanes, 'parallelism': 'member-sharded dp%d' % world},
         'kernel_ms': k_ms,
         'roofline': {'bound': 'hbm', 'achieved': ach_hbm / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
@@ -257,7 +297,7 @@ def main():
         'roofline_fp64': {'bound': 'valu-f64', 'achieved': ach_f64 / 1e12, 'peak': FP64_PEAK / 1e12, 'unit': 'TFLOP/s',
                           'frac': ach_f64 / FP64_PEAK},
         'roofline_issue': issue,
-        't_step_us': k_ms * 1e3 / T,
+        't_step_us': t_step_us,
         'value_host_buffers': value_host,      # this rank, inputs crossing PCIe per evaluation (informational)
     }
     res.update(res_extra)
@@ -266,12 +306,12 @@ def main():
         if mixed:
             rs_ = [builds.resolve_mode(m) for m in modes]
             build_of, faults_of = [r[0] for r in rs_], [list(r[1]) for r in rs_]
-        cb, fit_cpu, ls_cpu = cpu_baseline(w_host.numpy(), wl['hidden'], ref_host, moe, faults_of, build_of)
+        cb, fit_cpu, ls_cpu, n_chk = cpu_baseline(w_host.numpy(), wl['hidden'], ref_host, moe, faults_of, build_of)
         res['cpu_baseline'] = cb
-        fit_gpu = fit.cpu().numpy()
+        fit_gpu = fit.cpu().numpy()[:n_chk]
         rel = np.abs(fit_gpu - fit_cpu) / np.abs(fit_cpu)
-        res['parity_vs_cpu_port'] = {'max_rel_fitness': float(rel.max()),
-                                     'lengths_equal': bool((ls.cpu().numpy() == ls_cpu).all())}
+        res['parity_vs_cpu_port'] = {'max_rel_fitness': float(rel.max()), 'episodes_checked': int(n_chk),
+                                     'lengths_equal': bool((ls.cpu().numpy()[:n_chk] == ls_cpu).all())}
     print(json.dumps(res))
     if grouped:
         dist.destroy_process_group()

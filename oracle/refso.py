@@ -1,5 +1,5 @@
-"""ctypes binding of the REFERENCE's own prebuilt dynamics library.  TEST INFRASTRUCTURE, and only
-usable where /root/reference exists (this build container, not the GPU box).
+"""ctypes binding of the REFERENCE's own prebuilt dynamics library.  TEST INFRASTRUCTURE, and usable where
+/root/reference exists (this build container) or where oracle/build.py stage_ref() left its archive (oracle/_ref/).
 
 The cp38 SWIG module cannot be imported by Python 3.10, but ``ctypes.CDLL`` resolves its CPython
 symbols against the running interpreter and the raw C entry points ``initialize`` /
@@ -9,16 +9,34 @@ independent instance needs its own copy of the file.
 import ctypes, os, shutil, tempfile
 import numpy as np
 
-REF = os.environ.get('SERL_REFERENCE', '/root/reference')
 _D = ctypes.POINTER(ctypes.c_double)
+_ARCHIVE = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref', 'reference_path.zip')
+
+
+def reference_root():
+    """Where the reference lives: $SERL_REFERENCE, /root/reference (build container), or the archive oracle/build.py
+    stage_ref() packed into the git-ignored oracle/_ref/ (the GPU box).  None if none of them exists."""
+    for p in (os.environ.get('SERL_REFERENCE'), '/root/reference'):
+        if p and (os.path.isdir(os.path.join(p, 'envs', 'h2000_v90')) or (os.path.isfile(p) and p.endswith('.zip'))):
+            return p
+    return _ARCHIVE if os.path.isfile(_ARCHIVE) else None
+
+
+REF = reference_root() or '/root/reference'
 
 
 def available():
-    return os.path.isdir(os.path.join(REF, 'envs', 'h2000_v90'))
+    return reference_root() is not None
 
 
 def so_path(build):
-    return os.path.join(REF, 'envs', build, '_citation.cpython-38-x86_64-linux-gnu.so')
+    rel = 'envs/%s/_citation.cpython-38-x86_64-linux-gnu.so' % build
+    if os.path.isfile(REF):          # staged archive: shared objects cannot be loaded from inside a zip
+        import zipfile
+        d = tempfile.mkdtemp(prefix='refso_zip_')
+        with zipfile.ZipFile(REF) as z:
+            return z.extract(rel, d)
+    return os.path.join(REF, rel)
 
 
 class RefCitation:

@@ -166,16 +166,30 @@ __shared__ unsigned long long g_tlast;
 #define CITW_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
                          g_prof[(k)] += t_ - g_tlast; g_tlast = t_; } } while (0)
 __shared__ unsigned long long g_tlast1;       // same for wave 1 of the team kernels
+__shared__ unsigned long long g_tlastw[8];    // ... and for the other waves (barrier arrival / departure only)
+#if CITW_PROFILE == 2      // second profiling build: waves 4, 5, 6 report into the slots waves 1, 2, 3 use in the first
+#define CITW_U0() ((void)0)
+#define CITW_U(k) ((void)0)
+#define CITW_W0(w) ((void)0)
+#define CITW_W(w, k) ((void)0)
+#define CITW_V0(w) do { if (blockIdx.x == 0 && threadIdx.x == 64 * (w)) g_tlastw[(w)] = __builtin_readcyclecounter(); } while (0)
+#define CITW_V(w, k) do { if (blockIdx.x == 0 && threadIdx.x == 64 * (w)) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+                         g_prof[(k)] += t_ - g_tlastw[(w)]; g_tlastw[(w)] = t_; } } while (0)
+#else
+#define CITW_V0(w) ((void)0)
+#define CITW_V(w, k) ((void)0)
 #define CITW_U0() do { if (blockIdx.x == 0 && threadIdx.x == 64) g_tlast1 = __builtin_readcyclecounter(); } while (0)
 #define CITW_U(k) do { if (blockIdx.x == 0 && threadIdx.x == 64) { const unsigned long long t_ = __builtin_readcyclecounter(); \
                          g_prof[(k)] += t_ - g_tlast1; g_tlast1 = t_; } } while (0)
-__shared__ unsigned long long g_tlastw[4];    // ... and for waves 2, 3 (barrier arrival / departure only)
 #define CITW_W0(w) do { if (blockIdx.x == 0 && threadIdx.x == 64 * (w)) g_tlastw[(w)] = __builtin_readcyclecounter(); } while (0)
 #define CITW_W(w, k) do { if (blockIdx.x == 0 && threadIdx.x == 64 * (w)) { const unsigned long long t_ = __builtin_readcyclecounter(); \
                          g_prof[(k)] += t_ - g_tlastw[(w)]; g_tlastw[(w)] = t_; } } while (0)
+#endif
 #else
 #define CITW_W0(w) ((void)0)
 #define CITW_W(w, k) ((void)0)
+#define CITW_V0(w) ((void)0)
+#define CITW_V(w, k) ((void)0)
 #define CITW_T0() ((void)0)
 #define CITW_T(k) ((void)0)
 #define CITW_U0() ((void)0)

@@ -359,7 +359,6 @@ int serl_ga_distill(serl_ctx *c, float *child, int64_t stride, int32_t n_pairs, 
     return serl_fail(SERL_E_INVALID, "serl_ga_distill: bad argument");
   if (hidden != 32 || num_layers != 3 || state_dim < 1 || state_dim > DS_MAX || action_dim < 1 || action_dim > 4 || activation < 0 || activation > 2)
     return serl_fail(SERL_E_UNSUPPORTED, "serl_ga_distill: compiled for the SERL50 actor family (hidden 32, 3 hidden layers); other shapes train in PyTorch");
-  if (n_pairs == 0 || steps == 0) return SERL_OK;
   HIP_TRY(hipSetDevice(c->device));
   DistillArgs a;
   a.child = child; a.stride = stride; a.states = states; a.targets = targets; a.keep = keep; a.slots = slots; a.n_steps = n_steps;
@@ -367,6 +366,9 @@ int serl_ga_distill(serl_ctx *c, float *child, int64_t stride, int32_t n_pairs, 
   a.lr = lr; a.beta1 = 0.9f; a.beta2 = 0.999f; a.eps = 1e-8f;
   const int P = hidden * state_dim + hidden + num_layers * (hidden * hidden + 3 * hidden) + action_dim * hidden + action_dim;
   const size_t lds = ((size_t)4 * ((P + 3) & ~3) + (size_t)(num_layers + 3) * hidden * DB) * sizeof(float);
+  if (lds > (size_t)c->lds_per_block)
+    return serl_fail(SERL_E_UNSUPPORTED, "serl_ga_distill: the training state does not fit this device's LDS per workgroup; the caller trains pair by pair in PyTorch");
+  if (n_pairs == 0 || steps == 0) return SERL_OK;      // (n_pairs = 0 is the caller's probe: "would this shape run here?")
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(distill_kernel<32, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((distill_kernel<32, 3>), dim3(n_pairs), dim3(DB), lds, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());

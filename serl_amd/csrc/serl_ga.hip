@@ -153,7 +153,9 @@ __global__ void __launch_bounds__(256) ga_sensitivity_kernel(const float *weight
         }
         const float gmean = ga_block_sum(gh, f.red) / (float)H;
         const float gdotc = ga_block_sum(gh * czt, f.red);
-        if (t < H) dz[t] = (gh - gmean) / D - gdotc / (D * D) * czt / ((float)(H - 1) * sd);
+        // sd == 0 (all pre-LayerNorm values equal): torch's std_backward masks the term to 0 there, the reference stays finite
+        if (t < H) dz[t] = (gh - gmean) / D - (sd > 0.0f ? gdotc / (D * D) * czt / ((float)(H - 1) * sd) : 0.0f);
+
         __syncthreads();
         const float *prev = f.a + (size_t)l * H;
         float *Jl = J + offWl + (size_t)l * H * H;

@@ -125,6 +125,15 @@ def distil_batch(args, engine, spec, weights, pairs, buffers, critic, rng=random
         raise ValueError('distilation_crossover needs the learner\'s critic: SSNE(args, engine, spec, critic=...)')
     dev = weights.device
     fused = dev.type == 'cuda' and spec.hidden == 32 and spec.num_layers == 3 and spec.state_dim <= 16 and spec.action_dim <= 4
+    if fused and pairs:
+        # probe before any host draw is consumed: n_pairs = 0 returns SERL_E_UNSUPPORTED when the training state does not fit
+        # this device's LDS per workgroup (the fused kernel needs ~158 KB), and then the pairs train one by one in PyTorch
+        z = ctypes.c_void_p(0)
+        one = torch.zeros(4, dtype=torch.int32, device=dev)
+        rc = _capi.lib().serl_ga_distill(engine.ctx, weights.data_ptr(), weights.stride(0), 0, spec.state_dim, spec.hidden, spec.num_layers,
+                                         spec.action_dim, spec.activation_id, weights.data_ptr(), weights.data_ptr(), weights.data_ptr(), 1,
+                                         one.data_ptr(), 0, one.data_ptr(), one.data_ptr(), ctypes.c_float(1e-3), z)
+        fused = rc == 0
     if not fused or not pairs:
         return [distilation_crossover(args, engine, spec, weights, f, s, buffers, critic, rng) for f, s in pairs]
     P, S, A = spec.param_count, spec.state_dim, spec.action_dim

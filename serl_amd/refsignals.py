@@ -86,19 +86,20 @@ def gen_refs(t_max, amp_times, ampl_max, num_trails=10, rng=np.random):
     return refs
 
 
-def synthetic_reference_tables(n_episodes, num_evals, t_max=80, seed=7):
+def synthetic_reference_tables(n_episodes, num_evals, t_max=80, seed=7, first=0):
     """Benchmark references: episode 0 of every member flies the fixed base reference,
-    the others seeded smoothed-step sequences.  -> f64 [n_episodes, n_steps, 3] radians."""
+    the others seeded smoothed-step sequences.  -> f64 [n_episodes, n_steps, 3] radians.
+    first: global index of the first episode (a rank's block of one sharded population: episodes first .. first + n)."""
     n = n_steps_for(t_max)
     out = np.empty((n_episodes, n, 3))
     th0, ph0 = base_reference(t_max)
     base = tabulate(th0, ph0, t_max)
     tt = np.linspace(0.0, t_max, 6)
     for e in range(n_episodes):
-        if e % num_evals == 0:
+        if (first + e) % num_evals == 0:
             out[e] = base
             continue
-        rng = np.random.default_rng(seed + e)
+        rng = np.random.default_rng(seed + first + e)
         a_th = rng.choice(np.linspace(-12, 12, 6), size=6); a_th[0] = 0.0
         a_ph = rng.choice(np.linspace(-10, 10, 6), size=6)
         out[e] = tabulate(SmoothedStepSequence(tt, a_th, t_max // 10), SmoothedStepSequence(tt, a_ph, t_max // 10), t_max)

@@ -17,11 +17,18 @@ CPU generator), so selection, pairing and mutation targets are the reference's; 
 The reference's defaults (base/parameters.py:110-115: mut_type 'proximal', distil_crossover True, distil_type 'distance')
 are accepted.  Two reference defects on this path, and what happens here:
   * `random.randint(0, len(x))` is inclusive (mod_neuro_evo.py:51,517): with probability 1/(len+1) the reference raises
-    IndexError.  The draw is consumed (stream parity) and the last element taken instead; `self.clamped_draws` counts it.
+    IndexError.  The draw is consumed (stream parity) and the last element taken instead; `InclusiveRandint.count` -- a
+    class-level counter shared by every SSNE instance and every `plan_epoch` caller of the process -- counts it.
   * with distil_type 'distance' the stray line :505 overwrites the distance-sorted groups by
     `sort_groups_by_novelty(..., bcs_evals)`, which raises TypeError when `bcs_evals` is None (what Agent.train passes).
     Here: bcs_evals None -> the distance-sorted groups (the evident intent); bcs_evals given -> the novelty-sorted groups,
     like the reference (the distance draws are still consumed first).
+Two more deliberate deviations from the reference's behaviour in corner cases:
+  * `clone(master, replacee)` with master == replacee (an elite that is its own replacement slot) is a no-op here; the
+    reference's clone (:371-382) wipes the replacee's buffer and refills it from the master's -- which is the same, emptied,
+    object -- so there the elite loses its buffer.
+  * an Adam step of the fused distillation kernel whose Q-filter keeps no state of the minibatch is skipped; the reference
+    takes the mean over an empty selection (genetic_agent.py:44-59) and its child's weights become NaN.
 """
 import random
 import numpy as np

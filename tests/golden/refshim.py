@@ -13,8 +13,12 @@ the tests marked `needs_reference`.  Nothing here is imported by the product.
 import sys, types, os
 import numpy as np
 
-REF = os.environ.get('SERL_REFERENCE', '/root/reference')
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from oracle import refso as _refso
+# a directory (/root/reference, $SERL_REFERENCE) or the archive staged by oracle/build.py stage_ref() (zipimport)
+REF = _refso.REF
 
 
 def install(use_oracle_dynamics=False):

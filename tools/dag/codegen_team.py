@@ -340,8 +340,10 @@ class TeamGen(codegen.Gen):
             elif b == 1:
                 TM = lambda k: 'CITW_U(%d)' % (10 + k)
             else:
-                slots = {2: {0: 15, 1: 16, 2: 17, 3: 18}, 3: {0: 19, 1: 21, 2: 24, 3: 25}}.get(b, {})      # pre-B1, wait B1, post, wait B2
-                TM = lambda k: ('CITW_W(%d, %d)' % (b, slots[k])) if k in slots else '((void)0)'
+                slots = {2: {0: 15, 1: 16, 2: 17, 3: 18}, 3: {0: 19, 1: 21, 2: 24, 3: 25},       # pre-B1, wait B1, post, wait B2
+                         4: {0: 10, 1: 11, 2: 12, 3: 13}, 5: {0: 15, 1: 16, 2: 17, 3: 18}, 6: {0: 19, 1: 21, 2: 24, 3: 25}}.get(b, {})
+                mac = 'CITW_W' if b < 4 else 'CITW_V'      # waves 4 .. 6 report in the second profiling build (-DCITW_PROFILE=2), into the slots of waves 1 .. 3
+                TM = lambda k: ('%s(%d, %d)' % (mac, b, slots[k])) if k in slots else '((void)0)'
 
             def emit_node(n, allowed=None):
                 stack = [(n, False)]
@@ -512,7 +514,7 @@ class TeamGen(codegen.Gen):
             B('  const bool major = stage == 0;')
             B('  double STOP = 0.0;')
             B('  const int lane = threadIdx.x & 63;')
-            B('  %s;' % ('CITW_T0()' if b == 0 else ('CITW_U0()' if b == 1 else 'CITW_W0(%d)' % b)))
+            B('  %s;' % ('CITW_T0()' if b == 0 else ('CITW_U0()' if b == 1 else ('CITW_W0(%d)' if b < 4 else 'CITW_V0(%d)') % b)))
             # Derivative-block bank inputs: every wave reads the ones it needs before B1, the banks are rewritten after B1
             mine, st, seen = set(), list(self.pre_sinks[b]) + list(self.post_sinks[b]) + list(self.have[b]), set()
             st += [self.dw_out[k] for k, o in self.dw_owner.items() if o == b]

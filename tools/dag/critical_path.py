@@ -10,10 +10,15 @@ the measured 23 us per env step; six evaluations + one ODE5 combination make an 
                     4 cycles whatever its lanes hold, and four SIMDs share the work:
                         sum over nodes of instr(op) x 4 cycles / 4 SIMDs
                     with instr(op) = 1 for + - x, compares, logic; 2 for an f64 select (two v_cndmask); the measured
-                    instruction count of the compiler's IEEE division / sqrt expansion; look-ups and libm calls as the
-                    phases measured in profiles/ (they are lane-parallel: one pass serves all tables of a round).
+                    instruction count of the compiler's IEEE division / sqrt expansion; the lane-parallel phases (index
+                    search, interpolation passes, the libm bodies, table3) at their INSTRUCTION counts (PHASE_INSTR below:
+                    counted in the ISA of the shipped kernel, one pass serves all tables of a round) x 4 cycles.
   dependency floor  the longest chain of dependent operations, each at its measured dependent-issue latency
-                    (tools/valu_latency.hip): no partition of the DAG over wavefronts can finish sooner.
+                    (tools/valu_latency.hip): no partition of the DAG over wavefronts can finish sooner.  A table look-up
+                    counts with ITS OWN dependent chain -- input to the lanes, breakpoints, table values: three LDS round
+                    trips, then (z1-z0)/(x1-x0)*(u-x0)+z0 along x and again along y: two divisions and six additions /
+                    multiplications (one division and three for a 1-D table) -- not with the measured time of the current
+                    implementation's look-up phase (round 2 did that, which made the floor self-referential).
 """
 import os, sys, json, collections
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -23,15 +28,20 @@ LEAF = ('cf', 'ci', 'in', 'in_i', 'true', 'false', 'undef')
 # instructions per node (VALU issue slots)
 INSTR = dict(add=1, sub=1, mul=1, neg=1, fabs=1, sel=2, gt=1, ge=1, lt=1, le=1, eq=1, ne=1, band=1, bor=1, bnot=1, unord=1,
              div=13, sqrt=15)
-# lane-parallel phases of the wave-cooperative kernels, cycles per evaluation on the wave that runs them (profiles/r01_i,
-# r01_k: search 0.9 k, 2-D 0.75 k, 1-D 0.55 k for round 1; libm group ~0.9 k)
-PHASE = dict(lookup_round1=2200, lookup_round2=900, libm=900)
+# lane-parallel phases of the wave-cooperative kernels: instructions per evaluation on the wave that runs them, counted in the
+# ISA of the shipped team kernel (hipcc -S): index search over 22-entry rows / 13-entry rows, one 2-D pass, one 1-D pass per
+# round; the ocml bodies the evaluation calls once each (sincos, tan, exp, log10, pow: the calls of one function share a body);
+# table3.  A dependent chain through a libm body: ~40 dependent f64 operations (polynomial + reconstruction), pow twice that.
+PHASE_INSTR = dict(search_r1=70, l2d_r1=77, l1d_r1=32, search_r2=45, l2d_r2=77, l1d_r2=32, sincos=130, tan=140, exp=60, log10=120,
+                   pow=330, table3=186)
+LIBM_CHAIN_OPS = dict(pow=80, powsnf=80)
 LIBM = ('sc_sin', 'sc_cos', 'sin', 'cos', 'tan', 'exp', 'log10', 'log', 'atan', 'pow', 'powsnf')
 
 
 def main():
     variant = next((a for a in sys.argv[1:] if not a.startswith('--')), 'nominal')
-    lat = dict(dep_add_f64=8.0, dep_mul_f64=8.0, dep_div_f64=110.0, dep_sqrt_plus_add=120.0, cmp_select_add=20.0)
+    lat = dict(dep_add_f64=8.0, dep_mul_f64=8.0, dep_div_f64=110.0, dep_sqrt_plus_add=120.0, cmp_select_add=20.0,
+               lds_roundtrip_plus_add=93.0)
     if '--latency' in sys.argv:
         m = json.load(open(sys.argv[sys.argv.index('--latency') + 1]))
         lat.update({k: (v[1] if isinstance(v, list) else v) for k, v in m.items() if k != 'what'})
@@ -46,13 +56,17 @@ def main():
         stack.extend(build_dag.children(g, n))
     census = collections.Counter(g.nodes[n][0] for n in seen if g.nodes[n][0] not in LEAF)
     glue_instr = sum(INSTR.get(op, 1) * c for op, c in census.items() if op not in LIBM + ('l2d', 'l1d', 'table3'))
-    issue_cycles = glue_instr * 4 + sum(PHASE.values())
+    issue_cycles = glue_instr * 4 + 4 * sum(PHASE_INSTR.values())
     # dependent-latency weights (cycles)
     L_add, L_mul = lat['dep_add_f64'], lat['dep_mul_f64']
     W = dict(add=L_add, sub=L_add, mul=L_mul, neg=4, fabs=4, div=lat['dep_div_f64'], sqrt=lat['dep_sqrt_plus_add'] - L_add,
-             sel=lat['cmp_select_add'] - L_add, l2d=PHASE['lookup_round1'], l1d=PHASE['lookup_round1'], table3=400)
+             sel=lat['cmp_select_add'] - L_add)
+    L_lds = lat['lds_roundtrip_plus_add'] - L_add
+    W['l2d'] = 3 * L_lds + 2 * lat['dep_div_f64'] + 6 * L_add
+    W['l1d'] = 3 * L_lds + 1 * lat['dep_div_f64'] + 3 * L_add
+    W['table3'] = 2 * L_lds + 3 * lat['dep_div_f64'] + 12 * L_add
     for f in LIBM:
-        W[f] = PHASE['libm']
+        W[f] = LIBM_CHAIN_OPS.get(f, 40) * L_add
     depth, via = {}, {}
 
     def dep(n):
@@ -81,7 +95,10 @@ def main():
     out = dict(variant=variant, live_nodes=sum(census.values()), census=dict(census.most_common()),
                glue_instructions_min=glue_instr, issue_floor_cycles_per_eval_4_simds=issue_cycles / 4.0,
                dependency_floor_cycles_per_eval=depth[end], critical_chain=dict(chain.most_common()),
-               latencies_used={k: lat[k] for k in ('dep_add_f64', 'dep_mul_f64', 'dep_div_f64', 'dep_sqrt_plus_add', 'cmp_select_add')},
+               latencies_used={k: lat[k] for k in ('dep_add_f64', 'dep_mul_f64', 'dep_div_f64', 'dep_sqrt_plus_add', 'cmp_select_add',
+                                                   'lds_roundtrip_plus_add')},
+               chain_weights={k: round(W[k], 1) for k in ('l2d', 'l1d', 'table3', 'pow', 'sc_sin')},
+               phase_instructions=PHASE_INSTR,
                clock_ghz=2.4)
     per_step = lambda c: (6 * c) / 2.4e3
     out['issue_floor_us_per_env_step'] = per_step(out['issue_floor_cycles_per_eval_4_simds'])
