@@ -94,7 +94,7 @@ struct CitwLds {
   double inv[CITW_MAX_WAVES][CITW_INV_SLOTS];   // per-step invariants of the model (citw_<v>_step_invariants)
   double x[256];                          // team kernels: values that cross between the wavefronts at barrier B1
   double t3[48];
-  unsigned flag[8], iflag[8];             // hand-over flags of the team kernels (citw_flag_*, citw_iflag_*)
+  unsigned flag[16], iflag[16];           // hand-over flags of the team kernels (citw_flag_*, citw_iflag_*)
   alignas(16) float extra[CITW_LDS_EXTRA_FLOATS];     // unit-specific words (team kernels: actor hand-over + LDS-resident actor weights)
   double k[CITW_MAX_CONSTS];              // f64 literals of the model (only when generated with --lds-consts)
   CitwSearch S[CITW_MAX_ROUNDS][64];
@@ -153,8 +153,8 @@ __shared__ double g_bp[CITW_MAX_BPVEC][CITW_BP_PAD];   // the distinct breakpoin
 __shared__ CitwSearch g_S[CITW_MAX_ROUNDS][64];
 __shared__ CitwLookup g_L[CITW_MAX_ROUNDS][2][64];
 
-__shared__ alignas(64) unsigned g_flag[8];       // hand-over flags of the team kernels, one per producing wavefront (citw_flag_*)
-__shared__ alignas(64) unsigned g_iflag[8];      // ... and for look-up inputs computed by helper wavefronts (citw_iflag_*)
+__shared__ alignas(64) unsigned g_flag[16];      // hand-over flags of the team kernels, one per producing wavefront (citw_flag_*)
+__shared__ alignas(64) unsigned g_iflag[16];     // ... and for look-up inputs computed by helper wavefronts (citw_iflag_*)
 #endif
 
 // Phase profile of the model evaluation (profiling builds only, -DCITW_PROFILE): shader-clock cycles of wave 0 of
@@ -166,7 +166,7 @@ __shared__ unsigned long long g_tlast;
 #define CITW_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
                          g_prof[(k)] += t_ - g_tlast; g_tlast = t_; } } while (0)
 __shared__ unsigned long long g_tlast1;       // same for wave 1 of the team kernels
-__shared__ unsigned long long g_tlastw[8];    // ... and for the other waves (barrier arrival / departure only)
+__shared__ unsigned long long g_tlastw[16];    // ... and for the other waves (barrier arrival / departure only)
 #if CITW_PROFILE == 2      // second profiling build: waves 4, 5, 6 report into the slots waves 1, 2, 3 use in the first
 #define CITW_U0() ((void)0)
 #define CITW_U(k) ((void)0)
@@ -231,14 +231,25 @@ static __device__ __forceinline__ double citw_u2d(unsigned long long u) { return
 //   u <= x[0] -> 0 ; u >= x[n-1] -> n-2 ; u < 0: x[i] <= u < x[i+1] ; u >= 0: x[i] < u <= x[i+1]
 // The vectors are strictly increasing, so  lt = #{x_i < u}  is a position and  le = #{x_i <= u} = lt + (x[lt] == u);
 // rows of g_bp are padded with +inf, which no comparison below counts for finite u (and the clamp absorbs u = +inf).
-template <int MAXN>
-static __device__ __forceinline__ void citw_search_pass(const int wv, const CitwSearch *S, int lane);
+//
+// HINTED search.  The states move a little per RK stage and env step, so an input almost never leaves its interval between
+// two evaluations.  Every search has a slot of its own in g_sidx (SBASE + its number within the round; the rounds of an
+// evaluation do not overlap), which therefore still holds the index the previous evaluation found.  With c = (u < 0 ? le : lt)
+// the result is idx = clamp(c - 1, 0, n - 2), and idx == h holds exactly when
+//     (h == 0     or  x[h]   (<, <= for u < 0)  u)       [c - 1 >= h, or the lower clamp]
+// and (h == n - 2 or  not x[h+1] (<, <=) u)                [c - 1 <= h, or the upper clamp]
+// -- two LDS words and two compares instead of the whole row and 2 x MAXN operations.  The index is unique, so a verified hint
+// IS the result of the full count; if any lane of the wavefront fails the test (ballot) the wavefront runs the full count,
+// which also repairs the slot.  Slots start at 0 (staged by the kernels), any value is re-verified, NaN inputs fail every
+// compare and fall back to the count (idx 0, as before).
+template <int MAXN, int COUNT, int SBASE>
+static __device__ __forceinline__ void citw_search_pass(const int wv, const CitwSearch *S, int ln);
 // COUNT searches of one round, one per lane of the episode's lane group, in ceil(COUNT / CITW_GROUP_LANES) passes
-template <int MAXN, int COUNT = 64>
+template <int MAXN, int COUNT = 64, int SBASE = 0>
 static __device__ __forceinline__ void citw_search(const int wv, const CitwSearch *S, int lane)
 {
 #pragma unroll
-  for (int base = 0; base < COUNT; base += CITW_GROUP_LANES) citw_search_pass<MAXN>(wv, S, lane + base);
+  for (int base = 0; base < COUNT; base += CITW_GROUP_LANES) citw_search_pass<MAXN, COUNT, SBASE>(wv, S, lane + base);
 }
 
 // The passes PART, PART + NPARTS, ... of a search round (several episodes per team: helper wavefronts take passes beside wave 0)
@@ -246,21 +257,22 @@ static __device__ __forceinline__ void citw_search(const int wv, const CitwSearc
 #define CITW_L2_SHARE (64 / CITW_GROUP_LANES)
 #endif
 #define CITW_SEARCH_SHARE(count) (((count) + CITW_GROUP_LANES - 1) / CITW_GROUP_LANES < 3 ? ((count) + CITW_GROUP_LANES - 1) / CITW_GROUP_LANES : 3)
-template <int MAXN, int COUNT, int PART, int NPARTS>
+template <int MAXN, int COUNT, int PART, int NPARTS, int SBASE = 0>
 static __device__ __forceinline__ void citw_search_part(const int wv, const CitwSearch *S, int lane)
 {
 #pragma unroll
-  for (int base = PART * CITW_GROUP_LANES; base < COUNT; base += NPARTS * CITW_GROUP_LANES) citw_search_pass<MAXN>(wv, S, lane + base);
+  for (int base = PART * CITW_GROUP_LANES; base < COUNT; base += NPARTS * CITW_GROUP_LANES) citw_search_pass<MAXN, COUNT, SBASE>(wv, S, lane + base);
 }
 
+#ifndef CITW_SEARCH_HINT
+#define CITW_SEARCH_HINT 1
+#endif
+
+// the full count (the fallback of the hinted search, and the whole search with CITW_SEARCH_HINT = 0)
 template <int MAXN>
-static __device__ __forceinline__ void citw_search_pass(const int wv, const CitwSearch *S, int lane)
+static __device__ __forceinline__ int citw_search_count(const double *x, const int n, const double u)
 {
   typedef double v2d __attribute__((ext_vector_type(2)));
-  const CitwSearch d = S[lane];
-  const double u = g_in[wv][d.in];
-  const double *x = g_bp[d.row];
-  const int n = d.n;
 #if CITW_SEARCH_BATCH
   int lt = 0;
   // compares in batches of eight, then their additions: a compare result (an SGPR pair) may not be consumed by the very
@@ -295,7 +307,40 @@ static __device__ __forceinline__ void citw_search_pass(const int wv, const Citw
   int idx = ((u < 0.0) ? le : lt) - 1;
   idx = idx < 0 ? 0 : idx;
   idx = idx > n - 2 ? n - 2 : idx;
-  g_sidx[wv][lane] = idx;
+  return idx;
+}
+
+template <int MAXN, int COUNT, int SBASE>
+static __device__ __forceinline__ void citw_search_pass(const int wv, const CitwSearch *S, int ln)
+{
+  const bool valid = ln < COUNT;                      // (lanes beyond the round's searches hold a filler descriptor: they never store)
+  const int lc = valid ? ln : 0;
+  const CitwSearch d = S[lc];
+  int *slot = &g_sidx[wv][SBASE + lc];
+#if CITW_SEARCH_HINT
+  const int stored = *slot;
+#endif
+  const double u = g_in[wv][d.in];
+  const double *x = g_bp[d.row];
+  const int n = d.n;
+#if CITW_SEARCH_HINT
+  int h = stored < 0 ? 0 : stored;
+  h = h > n - 2 ? n - 2 : h;
+  const double xl = x[h], xh = x[h + 1];
+  const bool neg = u < 0.0;
+  const bool below = neg ? (xl <= u) : (xl < u);      // x[h] counts
+  const bool above = neg ? (xh <= u) : (xh < u);      // x[h + 1] counts too: the interval lies further up
+  const bool ok = ((h == 0) || below) && ((h == n - 2) || !above);
+  if (__builtin_expect(__ballot(valid && !ok) != 0ULL, 0)) {
+    const int idx = citw_search_count<MAXN>(x, n, u);
+    if (valid) *slot = idx;
+  } else if (valid && h != stored) {
+    *slot = h;
+  }
+#else
+  const int idx = citw_search_count<MAXN>(x, n, u);
+  if (valid) *slot = idx;
+#endif
 }
 
 template <typename OUT>

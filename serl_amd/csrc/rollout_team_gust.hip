@@ -2,7 +2,9 @@
 // (rollout_team.inc, gen/citation_gust_team.inc): the latency-bound regime, fewer episodes than CUs.
 #define CITW_SEARCH_BATCH 1
 #define CITW_MAX_WAVES 1          // one episode per workgroup: the team shares row 0 of every blackboard ...
+#ifndef CITW_M_ROWS
 #define CITW_M_ROWS 8             // ... except the libm results: one row per wavefront of the team
+#endif
 #define CITW_OUT2_ROWS 1
 #define CITW_INV_SLOTS 8
 #include "citation_wave.h"

@@ -129,6 +129,13 @@ class Gen:
             assert not any(g.nodes[a][0] in LOOKUPS for a in self.closure_all(n) if a != n), 'nested invariant look-ups'
         self.inv_round = make_round(inv_l2, inv_l1) if (inv_l2 or inv_l1) else None
         self.all_rounds = self.rounds + ([self.inv_round] if self.inv_round else [])
+        # every index search owns a slot of g_sidx for the whole episode (the hinted search of citation_wave.h re-verifies the
+        # interval the previous evaluation found): the rounds' slots follow each other
+        off = 0
+        for R in self.all_rounds:
+            R['sbase'] = off
+            off += len(R['searches'])
+        assert off <= 63, 'index-search slots of all rounds must fit g_sidx[.][64] (slot 63 stays 0 for the filler descriptors)'
         assert len(self.all_rounds) <= 3
         # ---- libm calls that depend on the states only (no look-up / libm ancestor): one lane per call
         LIBM = ('sc_sin', 'sc_cos', 'sin', 'cos', 'tan', 'exp', 'log10', 'log', 'atan', 'pow')
@@ -339,7 +346,7 @@ class Gen:
             for k, n in enumerate(R['ins']):
                 P('    g_in[wv][%d] = %s;' % (k, self.ref(n)))
             P('  }')
-            P('  citw_search<%d, %d>(wv, S[%d], lane);' % (R['maxn'], len(R['searches']), RI))
+            P('  citw_search<%d, %d, %d>(wv, S[%d], lane);' % (R['maxn'], len(R['searches']), R['sbase'], RI))
             if R['L2']:
                 P('  citw_lookup2d<%d>(wv, L[%d][0], g_out%d, lane);' % (len(R['L2']), RI, RI))
             if R['L1']:
@@ -374,7 +381,7 @@ class Gen:
         # ---- descriptor tables
         P('static __device__ const CitwSearch citw_%s_search[%d][64] = {' % (V, len(self.all_rounds)))
         for R in self.all_rounds:
-            rows = ['{%d, %d, %d, 0}' % (self.bpvec.index((s[0], s[1])), s[1], s[2]) for s in R['searches']]
+            rows = ['{%d, %d, %d, %d}' % (self.bpvec.index((s[0], s[1])), s[1], s[2], R['sbase'] + k) for k, s in enumerate(R['searches'])]
             rows += ['{0, 2, 0, 0}'] * (64 - len(rows))
             P('  {' + ', '.join(rows) + '},')
         P('};')
@@ -382,10 +389,10 @@ class Gen:
         P('static __device__ const CitwBpVec citw_%s_bpvec[%d] = {%s};' % (V, len(self.bpvec), ', '.join('{%d, %d}' % ((a >> 3) - lw, n) for a, n in self.bpvec)))
         P('static __device__ const CitwLookup citw_%s_lookup[%d][2][64] = {' % (V, len(self.all_rounds)))
         for R in self.all_rounds:
-            rows2 = ['{%d, %d, %d, %d, %d, %d, %d, %d, %d}' % ((e['xr'] >> 3) - lw, e['nr'], (e['xc'] >> 3) - lw, (e['z'] >> 3) - lw, e['sx'], e['sy'],
+            rows2 = ['{%d, %d, %d, %d, %d, %d, %d, %d, %d}' % ((e['xr'] >> 3) - lw, e['nr'], (e['xc'] >> 3) - lw, (e['z'] >> 3) - lw, R['sbase'] + e['sx'], R['sbase'] + e['sy'],
                                                                e['in0'], e['in1'], k) for k, e in enumerate(R['L2'])]
             rows2 += ['{0, 2, 0, 0, 63, 63, 0, 0, 127}'] * (64 - len(rows2))
-            rows1 = ['{%d, %d, 0, %d, %d, 0, %d, 0, %d}' % ((e['x'] >> 3) - lw, e['n'], (e['y'] >> 3) - lw, e['sx'], e['in0'], 64 + k)
+            rows1 = ['{%d, %d, 0, %d, %d, 0, %d, 0, %d}' % ((e['x'] >> 3) - lw, e['n'], (e['y'] >> 3) - lw, R['sbase'] + e['sx'], e['in0'], 64 + k)
                      for k, e in enumerate(R['L1'])]
             rows1 += ['{0, 2, 0, 0, 63, 0, 0, 0, 127}'] * (64 - len(rows1))
             P('  {{' + ', '.join(rows2) + '},')
@@ -480,7 +487,7 @@ class Gen:
             for k, n in enumerate(R['ins']):
                 P('    g_in[wv][%d] = %s;' % (k, self.ref(n)))
             P('  }')
-            P('  citw_search<%d, %d>(wv, S[%d], lane);' % (R['maxn'], len(R['searches']), r))
+            P('  citw_search<%d, %d, %d>(wv, S[%d], lane);' % (R['maxn'], len(R['searches']), R['sbase'], r))
             P('  CITW_T(%d);' % (4 * r + 1))
             if R['L2']:
                 P('  citw_lookup2d<%d>(wv, L[%d][0], g_out%d, lane);' % (len(R['L2']), r, r))

@@ -51,6 +51,7 @@ IMPORT_COST = float(os.environ.get('CITW_TEAM_IMPORT_COST', 0.0))         # unit
 # initial load per wave behind B1 (round 1, K = 4: the wave that hands the pow chain over needed a bias of 100 units; with two
 # wavefronts per SIMD the hardware evens that out and no bias measures best)
 POST_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_POST_BIAS', '0').split(',') if v]
+PRE_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_PRE_BIAS', '0').split(',') if v]        # initial load per wave in front of B1 (negative: the wave takes more; wave 3 shares its SIMD with the mostly parked actor wavefront)
 AFFINITY_POST = float(os.environ.get('CITW_TEAM_AFFINITY_POST', 0.0))
 SHARE_LIBM = int(os.environ.get('CITW_TEAM_SHARE_LIBM', 1))           # 1: every libm call is made by one wave, the others read the result (flag hand-over)
 SPREAD_IN = int(os.environ.get('CITW_TEAM_SPREAD_INPUTS', 0))         # 1: EVERY round-1 input cone runs on a helper; wave 0 waits for their input flags (g_iflag), then looks up
@@ -151,6 +152,8 @@ class TeamGen(codegen.Gen):
         A0w = self.closure([n for n in ins0 if self.in_owner[n] == 0 and n in S0], S0)       # wave 0's share of A0
         have = [set(A0w)] + [set() for _ in range(K - 1)]
         load = [sum(cost(m) for m in A0w) + fn_cost(A0w, 0, True) + LOOKUP_PHASES] + [0.0] * (K - 1)
+        for q, v in enumerate(PRE_BIAS[:K]):
+            load[q] += v
         self.h1d = 1 if (OFFLOAD_1D and K > 2 and self.rounds[0]['L1']) else None
         self.l2_helpers = L2_WAVES if (SHARE_2D and K >= 7 and self.h1d is not None and self.rounds[0]['L2']) else []
         if self.h1d is not None:
@@ -483,14 +486,14 @@ class TeamGen(codegen.Gen):
                     ns = len(R['searches'])
                     B('#if CITW_SEARCH_SHARE(%d) > 1   /* several episodes per team: the search passes are shared with waves 2 (and 4) */' % ns)
                     B('  citw_iflag_raise(7, %s);   /* the look-up inputs are in g_in[0] */' % SEQ)
-                    B('  citw_search_part<%d, %d, 0, CITW_SEARCH_SHARE(%d)>(wv, S[%d], lane);' % (R['maxn'], ns, ns, r))
+                    B('  citw_search_part<%d, %d, 0, CITW_SEARCH_SHARE(%d), %d>(wv, S[%d], lane);' % (R['maxn'], ns, ns, R['sbase'], r))
                     B('  citw_iflag_raise(0, %s);' % SEQ)
                     B('  citw_iflag_wait(%d, %s);' % (SEARCH_WAVES[0], SEQ))
                     B('#if CITW_SEARCH_SHARE(%d) > 2' % ns)
                     B('  citw_iflag_wait(%d, %s);' % (SEARCH_WAVES[1], SEQ))
                     B('#endif')
                     B('#else')
-                B('  citw_search<%d, %d>(wv, S[%d], lane);' % (R['maxn'], len(R['searches']), r))
+                B('  citw_search<%d, %d, %d>(wv, S[%d], lane);' % (R['maxn'], len(R['searches']), R['sbase'], r))
                 if r == 0 and self.h1d is not None:
                     B('  citw_iflag_raise(0, %s);   /* interval indices are in g_sidx[0]: wave %d runs the 1-D pass beside the 2-D pass */' % (SEQ, self.h1d))
                 if r == 0 and self.l2_helpers and SHARE_SEARCH:
@@ -581,7 +584,7 @@ class TeamGen(codegen.Gen):
                 nsq = len(self.rounds[0]['searches'])
                 B('#if CITW_SEARCH_SHARE(%d) > %d   /* several episodes per team: search pass %d, beside wave 0 */' % (nsq, kq, kq))
                 B('  citw_iflag_wait(7, %s);' % SEQ)
-                B('  citw_search_part<%d, %d, %d, CITW_SEARCH_SHARE(%d)>(0, S[0], lane);' % (self.rounds[0]['maxn'], nsq, kq, nsq))
+                B('  citw_search_part<%d, %d, %d, CITW_SEARCH_SHARE(%d), %d>(0, S[0], lane);' % (self.rounds[0]['maxn'], nsq, kq, nsq, self.rounds[0]['sbase']))
                 B('  citw_iflag_raise(%d, %s);' % (bb, SEQ))
                 B('#endif')
             B('  /* ---- share of this wave in the look-up independent glue */')
