@@ -416,6 +416,19 @@ static __device__ __forceinline__ void citw_lookup1d_pass(const int wv, const Ci
   out[wv][d.out] = r + y0;
 }
 
+// x / c for a literal c, rc = RN(1 / c): correctly rounded for every finite x whose quotient is a normal number -- proved per
+// divisor by tools/dag/constdiv.py (error of q + r rc against x / c below 2^-104; the finitely many x whose quotient lies that
+// close to a rounding boundary are enumerated and checked exactly), so the result is the IEEE quotient the reference computes.
+// v_div_fixup_f64 restores the IEEE result for zeros (sign), infinities and NaN.  4 instructions, ~30 dependent cycles
+// (IEEE division: 13 and ~71).  fma is explicit here; -ffp-contract=off only forbids the compiler to fuse on its own.
+static __device__ __forceinline__ double citw_div_const(const double x, const double c, const double rc)
+{
+  const double q = x * rc;
+  const double r = __builtin_fma(-q, c, x);
+  const double q2 = __builtin_fma(r, rc, q);
+  return __builtin_amdgcn_div_fixup(q2, c, x);
+}
+
 // ---- table3 S-function: 3-D table, linear interpolation.  The reference walks linearly from an interval cached in
 // IWORK/RWORK (part of rtDW, not observable through step()); the interval it ends on is
 // clamp(max{i : tab[i] < x}, 0, n-2) whatever the cache holds.
@@ -500,6 +513,50 @@ static __device__ __forceinline__ double citw_ode5_combine_st(const double (*f)[
   double acc = fv[0] * (citw_ode5_b(ST, 0) * h);
 #pragma unroll
   for (int j = 1; j <= ST; ++j) acc = acc + fv[j] * (citw_ode5_b(ST, j) * h);
+  return acc + yi;
+}
+
+// The same sum in two pieces (team kernels): the terms of the EARLIER stages are in LDS since the previous evaluation's last
+// barrier, so their loads and multiply-adds are issued in front of the evaluation and overlap it; behind the evaluation's
+// last barrier only the new stage's term and the state are added.  Same operations in the same order as citw_ode5_combine_st.
+template <int ST>
+static __device__ __forceinline__ double citw_ode5_partial_st(const double (*f)[20], int li)
+{
+  constexpr double h = 0.01;
+  if constexpr (ST == 0) return 0.0;
+  else {
+    double fv[ST];
+#pragma unroll
+    for (int j = 0; j < ST; ++j) fv[j] = f[j][li];
+    double acc = fv[0] * (citw_ode5_b(ST, 0) * h);
+#pragma unroll
+    for (int j = 1; j < ST; ++j) acc = acc + fv[j] * (citw_ode5_b(ST, j) * h);
+    return acc;
+  }
+}
+static __device__ __forceinline__ double citw_ode5_partial(int st, const double (*f)[20], int li)
+{
+  switch (st) {           // wave-uniform
+    case 0: return 0.0;
+    case 1: return citw_ode5_partial_st<1>(f, li);
+    case 2: return citw_ode5_partial_st<2>(f, li);
+    case 3: return citw_ode5_partial_st<3>(f, li);
+    case 4: return citw_ode5_partial_st<4>(f, li);
+    default: return citw_ode5_partial_st<5>(f, li);
+  }
+}
+static __device__ __forceinline__ double citw_ode5_finish(int st, double part, const double (*f)[20], int li, double yi)
+{
+  constexpr double h = 0.01;
+  const double fs = f[st][li];
+  double c = citw_ode5_b(0, 0) * h;                  // B[st][st] * h as scalar selects of literals (the products fold)
+  c = st == 1 ? citw_ode5_b(1, 1) * h : c;
+  c = st == 2 ? citw_ode5_b(2, 2) * h : c;
+  c = st == 3 ? citw_ode5_b(3, 3) * h : c;
+  c = st == 4 ? citw_ode5_b(4, 4) * h : c;
+  c = st >= 5 ? citw_ode5_b(5, 5) * h : c;
+  const double t = fs * c;
+  const double acc = st == 0 ? t : part + t;
   return acc + yi;
 }
 

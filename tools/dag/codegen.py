@@ -17,7 +17,11 @@ Usage: python tools/dag/codegen.py [variant ...]      (products are committed)
 """
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import build_dag, symex, interp
+import build_dag, symex, interp, constdiv
+from symex import f2b, b2f
+
+LAZY_LIBM = int(os.environ.get('CITW_LAZY_LIBM', 1))      # 1: libm calls whose result is used on one side of a select only run under its condition
+CONST_DIV = int(os.environ.get('CITW_CONST_DIV', 1))      # 1: divisions by literals as reciprocal multiply + fma correction (constdiv.py)
 
 LOOKUPS = ('l2d', 'l1d')
 
@@ -165,6 +169,40 @@ class Gen:
         for j, (key, outs) in enumerate(self.libm_calls):
             for which, node in outs.items():
                 self.libm_slot[node] = 2 * j + (0 if which == 'r0' else 1)
+        # ---- libm calls whose result is only ever used on ONE side of a select (the ISA atmosphere evaluates its troposphere
+        # power law and its stratosphere exponential and then picks one; log10 of the altitude only counts below 300 m): the
+        # call is guarded by the select's condition -- a wave-uniform branch around a 60 .. 330 instruction body.  need[n] is a
+        # conservative summary of "when does a root depend on n": True (always), or one literal (condition node, polarity).
+        self.call_guard = {}
+        if LAZY_LIBM:
+            rootset = set(self.roots)
+            need = {}
+            for n in reversed(self.order):
+                acc = True if n in rootset else None           # None: no user seen yet
+                for u in users[n]:
+                    nu = need.get(u)
+                    if nu is None:
+                        continue
+                    tu = g.nodes[u]
+                    via = nu
+                    if tu[0] == 'sel' and n != tu[1] and (tu[2] == n) != (tu[3] == n):
+                        lit = (tu[1], tu[2] == n)
+                        via = lit if nu is True else nu          # (either literal alone is a superset of their conjunction)
+                    if acc is None:
+                        acc = via
+                    elif acc is not True and acc != via:
+                        acc = True
+                    if acc is True:
+                        break
+                need[n] = acc
+            for j, (key, outs) in enumerate(self.libm_calls):
+                lits = {need.get(node) for node in outs.values()}
+                if len(lits) == 1:
+                    lit = lits.pop()
+                    if lit is not None and lit is not True:
+                        cone = self.closure_all(lit[0])
+                        if not any(g.nodes[m][0] in LIBM or g.nodes[m][0] in LOOKUPS or g.nodes[m][0] == 'table3' for m in cone):
+                            self.call_guard[j] = lit
         # distinct breakpoint vectors over all rounds -> rows of g_bp
         self.bpvec = []
         for R in self.all_rounds:
@@ -242,6 +280,13 @@ class Gen:
     FN1 = dict(sqrt='sqrt', exp='exp', log10='log10', log='log', sin='sin', cos='cos', tan='tan', atan='atan', asin='asin',
                acos='acos', floor='floor', fabs='fabs')
 
+    _cdiv = {}
+
+    def const_div_ok(self, bits):
+        if bits not in Gen._cdiv:
+            Gen._cdiv[bits] = constdiv.verify(b2f(bits))[0]
+        return Gen._cdiv[bits]
+
     def stmt(self, n):
         g = self.g
         t = g.nodes[n]
@@ -253,7 +298,12 @@ class Gen:
         name = R(n)
         if n in self.libm_slot:
             return '  %s %s = g_m[wv][%d];' % (ty, name, self.libm_slot[n])
-        if op in self.BIN:
+        if op == 'div' and CONST_DIV and g.nodes[t[2]][0] == 'cf' and self.const_div_ok(g.nodes[t[2]][1]):
+            # division by a literal: multiply by the correctly rounded reciprocal + one fma correction step, correctly
+            # rounded for every dividend (tools/dag/constdiv.py proves it per divisor); 4 instructions instead of 13
+            c = b2f(g.nodes[t[2]][1])
+            e = 'citw_div_const(%s, %s, %s)' % (R(t[1]), hexf(g.nodes[t[2]][1]), hexf(f2b(constdiv.recip(c))))
+        elif op in self.BIN:
             e = '%s %s %s' % (R(t[1]), self.BIN[op], R(t[2]))
         elif op == 'neg':
             e = '-%s' % R(t[1])
@@ -451,6 +501,8 @@ class Gen:
             P('  /* ---- libm calls that depend on the states only: one lane per call (the branches of one function run together) */')
             for (fn, arg, prm), outs in self.libm_calls:
                 emit_node(arg)
+            for j in sorted(self.call_guard):
+                emit_node(self.call_guard[j][0])         # the condition under which call j's result is used at all
             P('  if (lane == 0) {')
             for j, ((fn, arg, prm), outs) in enumerate(self.libm_calls):
                 P('    g_in[wv][%d] = %s;' % (j, self.ref(arg)))
@@ -466,6 +518,8 @@ class Gen:
                 while k < len(self.libm_calls) and self.libm_calls[k][0][0] == fn and (fn != 'pow' or self.libm_calls[k][0][2] == prm):
                     k += 1
                 cond = '(lane >= %d && lane < %d)' % (j, k) if k - j > 1 else '(lane == %d)' % j
+                if k - j == 1 and j in self.call_guard:
+                    cond = '(lane == %d && %s%s)' % (j, '' if self.call_guard[j][1] else '!', self.ref(self.call_guard[j][0]))
                 call = {'sincos': 'sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = pow(a_, %s)' % hexf(prm)}.get(fn, 'r0_ = %s(a_)' % fn)
                 P('    %sif %s { %s; }' % ('' if first else 'else ', cond, call))
                 first = False

@@ -105,7 +105,9 @@ class TeamGen(codegen.Gen):
         rootset = set(roots)
         later_use = lambda n: any((u not in S0) for u in users[n])
         sinks = [n for n in self.order if n in S0 and n not in A0 and (later_use(n) or n in rootset)]
-        cost = lambda n: 0 if g.nodes[n][0] in FN else 2 * CW.get(g.nodes[n][0], 1)
+        cdiv = lambda n: (g.nodes[n][0] == 'div' and codegen.CONST_DIV and g.nodes[g.nodes[n][2]][0] == 'cf'
+                          and self.const_div_ok(g.nodes[g.nodes[n][2]][1]))
+        cost = lambda n: 0 if g.nodes[n][0] in FN else (2 * 4 if cdiv(n) else 2 * CW.get(g.nodes[n][0], 1))
         fns = [set() for _ in range(K)]
         self.shared_libm = set(self.libm_slot) if (SHARE_LIBM and K > 1) else set()
         shared = self.shared_libm
@@ -392,6 +394,9 @@ class TeamGen(codegen.Gen):
                 B('  /* ---- libm calls this wave makes for the team: one lane per call, results in g_m[%d] */' % b)
                 for j in calls:
                     emit_node(self.libm_calls[j][0][1])
+                for j in calls:
+                    if j in self.call_guard:
+                        emit_node(self.call_guard[j][0])     # the condition under which this call's result is used at all
                 B('  if (lane == 0) {')
                 for j in calls:
                     B('    g_m[%d][%d] = %s;' % (b, 48 + self.calls_of[b].index(j), self.ref(self.libm_calls[j][0][1])))
@@ -409,6 +414,9 @@ class TeamGen(codegen.Gen):
                     while k < len(calls) and self.libm_calls[calls[k]][0][0] == fn and (fn != 'pow' or self.libm_calls[calls[k]][0][2] == prm):
                         k += 1
                     cond = '(l_ >= %d && l_ < %d)' % (i, k) if k - i > 1 else '(l_ == %d)' % i
+                    if k - i == 1 and calls[i] in self.call_guard:
+                        gd = self.call_guard[calls[i]]
+                        cond = '(l_ == %d && %s%s)' % (i, '' if gd[1] else '!', self.ref(gd[0]))
                     call = {'sincos': 'sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = pow(a_, %s)' % hexf(prm)}.get(fn, 'r0_ = %s(a_)' % fn)
                     B('    %sif %s { %s; }' % ('' if first else 'else ', cond, call))
                     first = False
