@@ -37,12 +37,14 @@
 #define CITW_TROW 0
 #define CITW_MROW(q) (q)
 #define CITW_XOFF 0
+#define CITW_YOFF 0
 #define CITW_GROUPS 1
 #else
 #define CITW_GROUPS (64 / CITW_GROUP_LANES)                      // 2 or 4 episodes per wavefront
 #define CITW_TROW ((int)((threadIdx.x & 63) / CITW_GROUP_LANES))
 #define CITW_MROW(q) ((q) * CITW_GROUPS + CITW_TROW)
 #define CITW_XOFF (CITW_TROW * (256 / CITW_GROUPS))
+#define CITW_YOFF (CITW_TROW * 32)
 #endif
 #ifndef CITW_SEARCH_BATCH
 #define CITW_SEARCH_BATCH 0     // 1 (team kernels): index-search compares in batches of eight; costs 44 VGPRs, which the one-wave kernels lack
@@ -94,6 +96,7 @@ struct CitwLds {
   double inv[CITW_MAX_WAVES][CITW_INV_SLOTS];   // per-step invariants of the model (citw_<v>_step_invariants)
   double x[256];                          // team kernels: values that cross between the wavefronts at barrier B1
   double t3[48];
+  unsigned pflag[16]; double y[32 * CITW_GROUPS];
   unsigned flag[16], iflag[16];           // hand-over flags of the team kernels (citw_flag_*, citw_iflag_*)
   alignas(16) float extra[CITW_LDS_EXTRA_FLOATS];     // unit-specific words (team kernels: actor hand-over + LDS-resident actor weights)
   double k[CITW_MAX_CONSTS];              // f64 literals of the model (only when generated with --lds-consts)
@@ -119,6 +122,8 @@ __shared__ CitwLds citw_lds;
 #define g_t3 citw_lds.t3
 #define g_flag citw_lds.flag
 #define g_iflag citw_lds.iflag
+#define g_pflag citw_lds.pflag
+#define g_y citw_lds.y
 #define g_k citw_lds.k
 #define g_S citw_lds.S
 #define g_L citw_lds.L
@@ -155,6 +160,8 @@ __shared__ CitwLookup g_L[CITW_MAX_ROUNDS][2][64];
 
 __shared__ alignas(64) unsigned g_flag[16];      // hand-over flags of the team kernels, one per producing wavefront (citw_flag_*)
 __shared__ alignas(64) unsigned g_iflag[16];     // ... and for look-up inputs computed by helper wavefronts (citw_iflag_*)
+__shared__ alignas(64) unsigned g_pflag[16];     // ... and for the values of the task graph behind the look-ups (citw_pflag_*)
+__shared__ alignas(64) double g_y[32 * CITW_GROUPS];   // team kernels: values that cross between the wavefronts BEHIND barrier B1 (task graph)
 #endif
 
 // Phase profile of the model evaluation (profiling builds only, -DCITW_PROFILE): shader-clock cycles of wave 0 of
@@ -224,6 +231,19 @@ static __device__ __forceinline__ void citw_iflag_wait(int q, unsigned seq)
   while ((int)(__hip_atomic_load(&g_iflag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) __builtin_amdgcn_s_sleep(1);
 }
 
+// ... and a third for the task graph behind the look-ups (gen/citation_<v>_team.inc): wave q announces its k-th published value
+// of the evaluation with sequence number SEQ by g_pflag[q] = SEQ * 16 + k; the value itself is in g_y
+static __device__ __forceinline__ void citw_pflag_raise(int q, unsigned seq)
+{
+  seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(&g_pflag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+static __device__ __forceinline__ void citw_pflag_wait(int q, unsigned seq)
+{
+  seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);
+  while ((int)(__hip_atomic_load(&g_pflag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) __builtin_amdgcn_s_sleep(1);
+}
+
 static __device__ __forceinline__ unsigned long long citw_d2u(double d) { return (unsigned long long)__double_as_longlong(d); }
 static __device__ __forceinline__ double citw_u2d(unsigned long long u) { return __longlong_as_double((long long)u); }
 
@@ -266,6 +286,10 @@ static __device__ __forceinline__ void citw_search_part(const int wv, const Citw
 
 #ifndef CITW_SEARCH_HINT
 #define CITW_SEARCH_HINT 1
+#endif
+#ifndef CITW_FUSED_LOOKUP
+#define CITW_FUSED_LOOKUP 0      // 1: look-up lanes verify their own hints (citw_lookup*_fused), no search pass.  Measured SLOWER (r03 sweep 6: 21.4 vs
+                                 // 20.3 us per env step; intervals change in 0.2 % of the evaluations, so it is not the fall-back): off
 #endif
 
 // the full count (the fallback of the hinted search, and the whole search with CITW_SEARCH_HINT = 0)
@@ -384,9 +408,79 @@ static __device__ __forceinline__ void citw_lookup2d_pass(const int wv, const Ci
   out[wv][d.out] = r + a;
 }
 
+// ---- FUSED hinted look-ups (one episode per wavefront / team: the lane group is the whole wavefront).  A look-up lane
+// re-verifies the hints of its own one or two index searches -- the words x[h], x[h+1] it needs for that ARE the interval
+// ends the interpolation uses -- and interpolates at once: no search pass, no round trip through g_sidx.  If any lane of the
+// wavefront fails the test the wavefront falls back to the search pass (which repairs the slots) and the plain pass; the
+// interval is unique, so both paths compute the same expression on the same operands.
+static __device__ __forceinline__ bool citw_hint_ok(const int h, const int n, const double xl, const double xh, const double u)
+{
+  const bool neg = u < 0.0;
+  const bool below = neg ? (xl <= u) : (xl < u);      // x[h] counts
+  const bool above = neg ? (xh <= u) : (xh < u);      // x[h + 1] counts too: the interval lies further up
+  return ((h == 0) || below) && ((h == n - 2) || !above);
+}
+
+template <int COUNT, int SMAXN, int SCOUNT, int SBASE, typename OUT>
+static __device__ __forceinline__ void citw_lookup2d_fused(const int wv, const CitwSearch *S, const CitwLookup *L, OUT &out, int lane)
+{
+  static_assert(COUNT <= 64, "one pass");
+  const bool valid = lane < COUNT;
+  const CitwLookup d = L[valid ? lane : 0];
+  int hx = g_sidx[wv][d.sx], hy = g_sidx[wv][d.sy];
+  const double u0 = g_in[wv][d.in0], u1 = g_in[wv][d.in1];
+  const int nr = d.nr, nc = d.p0;
+  hx = hx < 0 ? 0 : hx; hx = hx > nr - 2 ? nr - 2 : hx;
+  hy = hy < 0 ? 0 : hy; hy = hy > nc - 2 ? nc - 2 : hy;
+  const double *xr = g_ro + d.xrw, *xc = g_ro + d.xcw, *z = g_ro + d.zw;
+  const double x0 = xr[hx], x1 = xr[hx + 1];
+  const double y0 = xc[hy], y1 = xc[hy + 1];
+  const double z00 = z[hx + nr * hy], z10 = z[hx + 1 + nr * hy];
+  const double z01 = z[hx + nr * (hy + 1)], z11 = z[hx + 1 + nr * (hy + 1)];
+  const bool ok = citw_hint_ok(hx, nr, x0, x1, u0) && citw_hint_ok(hy, nc, y0, y1, u1);
+  const double dx = x1 - x0, wx = u0 - x0;
+  double a = z10 - z00; a = a / dx; a = a * wx; a = a + z00;
+  double b = z11 - z01; b = b / dx; b = b * wx; b = b + z01;
+  const double dy = y1 - y0;
+  double r = b - a; r = r / dy; r = r * (u1 - y0);
+  if (__builtin_expect(__ballot(valid && !ok) == 0ULL, 1)) {
+    if (valid) out[wv][d.out] = r + a;
+  } else {
+    citw_search<SMAXN, SCOUNT, SBASE>(wv, S, lane);
+    citw_lookup2d<COUNT>(wv, L, out, lane);
+  }
+}
+
 template <typename OUT>
 static __device__ __forceinline__ void citw_lookup1d_pass(const int wv, const CitwLookup *L, OUT &out, int lane);
 template <int COUNT = 64, typename OUT>
+static __device__ __forceinline__ void citw_lookup1d(const int wv, const CitwLookup *L, OUT &out, int lane);
+
+template <int COUNT, int SMAXN, int SCOUNT, int SBASE, typename OUT>
+static __device__ __forceinline__ void citw_lookup1d_fused(const int wv, const CitwSearch *S, const CitwLookup *L, OUT &out, int lane)
+{
+  static_assert(COUNT <= 64, "one pass");
+  const bool valid = lane < COUNT;
+  const CitwLookup d = L[valid ? lane : 0];
+  int h = g_sidx[wv][d.sx];
+  const double u = g_in[wv][d.in0];
+  const int n = d.nr;
+  h = h < 0 ? 0 : h; h = h > n - 2 ? n - 2 : h;
+  const double *x = g_ro + d.xrw, *y = g_ro + d.zw;
+  const double x0 = x[h], x1 = x[h + 1], y0 = y[h], y1 = y[h + 1];
+  const bool ok = citw_hint_ok(h, n, x0, x1, u);
+  double r = y1 - y0;
+  r = r / (x1 - x0);
+  r = r * (u - x0);
+  if (__builtin_expect(__ballot(valid && !ok) == 0ULL, 1)) {
+    if (valid) out[wv][d.out] = r + y0;
+  } else {
+    citw_search<SMAXN, SCOUNT, SBASE>(wv, S, lane);
+    citw_lookup1d<COUNT>(wv, L, out, lane);
+  }
+}
+
+template <int COUNT, typename OUT>
 static __device__ __forceinline__ void citw_lookup1d(const int wv, const CitwLookup *L, OUT &out, int lane)
 {
 #pragma unroll

@@ -39,8 +39,9 @@ def hexf(bits):
 
 
 class Gen:
-    def __init__(self, variant, fast_zero=True, lds_consts=False, lane_libm=True, lazy_loads=False, hoist=False):
+    def __init__(self, variant, fast_zero=True, lds_consts=False, lane_libm=True, lazy_loads=False, hoist=False, split_chain=False):
         self.variant = variant
+        self.split_chain = split_chain
         self.hoist = hoist
         self.lazy_loads = lazy_loads
         self.lane_libm = lane_libm
@@ -127,12 +128,43 @@ class Gen:
             l2 = [n for n in self.order if g.nodes[n][0] == 'l2d' and self.rnd[n] == r and not self.inv[n]]
             l1 = [n for n in self.order if g.nodes[n][0] == 'l1d' and self.rnd[n] == r and not self.inv[n]]
             self.rounds.append(make_round(l2, l1))
+        # ---- the look-up CHAIN (team kernels, split_chain): first-round look-ups that only feed derivatives which also need the
+        # second round -- the engine model: thrust tables -> (divide by the air-data ratio) -> spool-speed tables -> N1 / N2
+        # derivatives.  Nothing else waits for them, so a wavefront of its own walks that chain (chain round -> second round ->
+        # engine derivatives) beside the aerodynamic look-ups instead of behind them.  The chain round shares the blackboards of
+        # round 1 (g_in, g_sidx, g_out0) with slot ranges of its own (ibase / sbase / obase*).
+        self.chain_round = None
+        if split_chain and self.nrounds == 2:
+            late = [r for r in self.roots if self.rnd[r] >= 2]
+            anc_other = set()
+            for r in self.roots:
+                if self.rnd[r] < 2:
+                    anc_other |= self.closure_all(r)
+            is_l = lambda n, op: g.nodes[n][0] == op and self.rnd[n] == 1 and not self.inv[n]
+            chain = [n for n in self.order if (is_l(n, 'l2d') or is_l(n, 'l1d')) and n not in anc_other]
+            if chain and late:
+                cs = set(chain)
+                self.rounds[0] = make_round([n for n in self.order if is_l(n, 'l2d') and n not in cs],
+                                            [n for n in self.order if is_l(n, 'l1d') and n not in cs])
+                self.chain_round = make_round([n for n in chain if g.nodes[n][0] == 'l2d'], [n for n in chain if g.nodes[n][0] == 'l1d'])
+        for r, R in enumerate(self.rounds):
+            R.update(ibase=0, obase2=0, obase1=0, oarr=r)
+        if self.chain_round is not None:
+            R0, RC = self.rounds[0], self.chain_round
+            RC.update(ibase=len(R0['ins']), obase2=len(R0['L2']), obase1=len(R0['L1']), oarr=0)
+            self.rounds[1]['ibase'] = len(R0['ins']) + len(RC['ins'])         # the second round runs beside round 1 now
+            assert self.rounds[1]['ibase'] + len(self.rounds[1]['ins']) <= 32
+            assert RC['obase2'] + len(RC['L2']) <= 64 and RC['obase1'] + len(RC['L1']) <= 64
         inv_l2 = [n for n in self.order if g.nodes[n][0] == 'l2d' and self.inv[n]]
         inv_l1 = [n for n in self.order if g.nodes[n][0] == 'l1d' and self.inv[n]]
         for n in inv_l2 + inv_l1:            # one invariant look-up round: their inputs must not need another look-up
             assert not any(g.nodes[a][0] in LOOKUPS for a in self.closure_all(n) if a != n), 'nested invariant look-ups'
         self.inv_round = make_round(inv_l2, inv_l1) if (inv_l2 or inv_l1) else None
-        self.all_rounds = self.rounds + ([self.inv_round] if self.inv_round else [])
+        if self.inv_round:
+            self.inv_round.update(ibase=0, obase2=0, obase1=0, oarr=len(self.rounds))
+        self.all_rounds = self.rounds + ([self.inv_round] if self.inv_round else []) + ([self.chain_round] if self.chain_round else [])
+        for ti, R in enumerate(self.all_rounds):
+            R['tidx'] = ti                     # row of the descriptor tables (g_S / g_L)
         # every index search owns a slot of g_sidx for the whole episode (the hinted search of citation_wave.h re-verifies the
         # interval the previous evaluation found): the rounds' slots follow each other
         off = 0
@@ -211,11 +243,11 @@ class Gen:
                     self.bpvec.append((xa, n))
         assert len(self.bpvec) <= 48 and max(n for _, n in self.bpvec) <= 23
         self.outslot = {}
-        for r, R in enumerate(self.all_rounds):
+        for R in self.all_rounds:
             for k, e in enumerate(R['L2']):
-                self.outslot[e['node']] = (r, k)
+                self.outslot[e['node']] = (R['oarr'], R['obase2'] + k)
             for k, e in enumerate(R['L1']):
-                self.outslot[e['node']] = (r, 64 + k)
+                self.outslot[e['node']] = (R['oarr'], 64 + R['obase1'] + k)
 
     def closure_all(self, n):
         out, st = set(), [n]
@@ -414,6 +446,33 @@ class Gen:
         P('}')
         return [ln.replace('g_cmd[wv]', 'g_cmd[sv]').replace('g_xs[wv]', 'g_xs[sv]') for ln in out]
 
+    def table_lines(self, pre):
+        """descriptor tables of the look-up rounds (index searches, 2-D / 1-D tables, distinct breakpoint vectors) as `pre`_search /
+        _lookup / _bpvec / _NBP"""
+        out = []
+        P = out.append
+        lw = self.low
+        P('static __device__ const CitwSearch %s_search[%d][64] = {' % (pre, len(self.all_rounds)))
+        for R in self.all_rounds:
+            rows = ['{%d, %d, %d, %d}' % (self.bpvec.index((s[0], s[1])), s[1], R['ibase'] + s[2], R['sbase'] + k) for k, s in enumerate(R['searches'])]
+            rows += ['{0, 2, 0, 0}'] * (64 - len(rows))
+            P('  {' + ', '.join(rows) + '},')
+        P('};')
+        P('enum { %s_NBP = %d };' % (pre, len(self.bpvec)))
+        P('static __device__ const CitwBpVec %s_bpvec[%d] = {%s};' % (pre, len(self.bpvec), ', '.join('{%d, %d}' % ((a >> 3) - lw, n) for a, n in self.bpvec)))
+        P('static __device__ const CitwLookup %s_lookup[%d][2][64] = {' % (pre, len(self.all_rounds)))
+        for R in self.all_rounds:
+            rows2 = ['{%d, %d, %d, %d, %d, %d, %d, %d, %d, %d}' % ((e['xr'] >> 3) - lw, e['nr'], (e['xc'] >> 3) - lw, (e['z'] >> 3) - lw, R['sbase'] + e['sx'], R['sbase'] + e['sy'],
+                                                                   R['ibase'] + e['in0'], R['ibase'] + e['in1'], R['obase2'] + k, e['nc']) for k, e in enumerate(R['L2'])]
+            rows2 += ['{0, 2, 0, 0, 63, 63, 0, 0, 127, 2}'] * (64 - len(rows2))
+            rows1 = ['{%d, %d, 0, %d, %d, 0, %d, 0, %d}' % ((e['x'] >> 3) - lw, e['n'], (e['y'] >> 3) - lw, R['sbase'] + e['sx'], R['ibase'] + e['in0'], 64 + R['obase1'] + k)
+                     for k, e in enumerate(R['L1'])]
+            rows1 += ['{0, 2, 0, 0, 63, 0, 0, 0, 127}'] * (64 - len(rows1))
+            P('  {{' + ', '.join(rows2) + '},')
+            P('   {' + ', '.join(rows1) + '}},')
+        P('};')
+        return out
+
     def emit(self):
         g = self.g
         V = self.variant
@@ -427,27 +486,8 @@ class Gen:
         P('#define CITW_%s_ROUNDS %d' % (V.upper(), len(self.all_rounds)))
         P('enum { citw_%s_ROUNDS = %d, citw_%s_RO_BASE_W = %d, citw_%s_RO_LO_W = %d, citw_%s_RO_HI_W = %d };  /* f64 word range of .rodata the model reads */'
           % (V, len(self.all_rounds), V, self.ro_base >> 3, V, self.ro_lo >> 3, V, self.ro_hi >> 3))
-        lw = self.low
-        # ---- descriptor tables
-        P('static __device__ const CitwSearch citw_%s_search[%d][64] = {' % (V, len(self.all_rounds)))
-        for R in self.all_rounds:
-            rows = ['{%d, %d, %d, %d}' % (self.bpvec.index((s[0], s[1])), s[1], s[2], R['sbase'] + k) for k, s in enumerate(R['searches'])]
-            rows += ['{0, 2, 0, 0}'] * (64 - len(rows))
-            P('  {' + ', '.join(rows) + '},')
-        P('};')
-        P('enum { citw_%s_NBP = %d };' % (V, len(self.bpvec)))
-        P('static __device__ const CitwBpVec citw_%s_bpvec[%d] = {%s};' % (V, len(self.bpvec), ', '.join('{%d, %d}' % ((a >> 3) - lw, n) for a, n in self.bpvec)))
-        P('static __device__ const CitwLookup citw_%s_lookup[%d][2][64] = {' % (V, len(self.all_rounds)))
-        for R in self.all_rounds:
-            rows2 = ['{%d, %d, %d, %d, %d, %d, %d, %d, %d}' % ((e['xr'] >> 3) - lw, e['nr'], (e['xc'] >> 3) - lw, (e['z'] >> 3) - lw, R['sbase'] + e['sx'], R['sbase'] + e['sy'],
-                                                               e['in0'], e['in1'], k) for k, e in enumerate(R['L2'])]
-            rows2 += ['{0, 2, 0, 0, 63, 63, 0, 0, 127}'] * (64 - len(rows2))
-            rows1 = ['{%d, %d, 0, %d, %d, 0, %d, 0, %d}' % ((e['x'] >> 3) - lw, e['n'], (e['y'] >> 3) - lw, R['sbase'] + e['sx'], e['in0'], 64 + k)
-                     for k, e in enumerate(R['L1'])]
-            rows1 += ['{0, 2, 0, 0, 63, 0, 0, 0, 127}'] * (64 - len(rows1))
-            P('  {{' + ', '.join(rows2) + '},')
-            P('   {' + ', '.join(rows1) + '}},')
-        P('};')
+        for line in self.table_lines('citw_%s' % V):
+            P(line)
         for line in self.emit_invariants():
             P(line)
         # ---- the evaluation function
@@ -541,6 +581,16 @@ class Gen:
             for k, n in enumerate(R['ins']):
                 P('    g_in[wv][%d] = %s;' % (k, self.ref(n)))
             P('  }')
+            sa = (R['maxn'], len(R['searches']), R['sbase'])
+            P('#if CITW_GROUP_LANES == 64 && CITW_FUSED_LOOKUP   /* the look-up lanes verify the hints of their own index searches */')
+            P('  CITW_T(%d);' % (4 * r + 1))
+            if R['L2']:
+                P('  citw_lookup2d_fused<%d, %d, %d, %d>(wv, S[%d], L[%d][0], g_out%d, lane);' % ((len(R['L2']),) + sa + (r, r, r)))
+            P('  CITW_T(%d);' % (4 * r + 2))
+            if R['L1']:
+                P('  citw_lookup1d_fused<%d, %d, %d, %d>(wv, S[%d], L[%d][1], g_out%d, lane);' % ((len(R['L1']),) + sa + (r, r, r)))
+            P('  CITW_T(%d);' % (4 * r + 3))
+            P('#else')
             P('  citw_search<%d, %d, %d>(wv, S[%d], lane);' % (R['maxn'], len(R['searches']), R['sbase'], r))
             P('  CITW_T(%d);' % (4 * r + 1))
             if R['L2']:
@@ -549,6 +599,7 @@ class Gen:
             if R['L1']:
                 P('  citw_lookup1d<%d>(wv, L[%d][1], g_out%d, lane);' % (len(R['L1']), r, r))
             P('  CITW_T(%d);' % (4 * r + 3))
+            P('#endif')
             done_rounds.add(r)
             if not self.lazy_loads:
                 for e in R['L2'] + R['L1']:

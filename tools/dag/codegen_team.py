@@ -43,6 +43,7 @@ import build_dag, codegen
 from codegen import LOOKUPS, hexf
 
 LEAF = ('cf', 'ci', 'in', 'in_i', 'true', 'false')
+TASKS_UNSPLIT = set()
 TEAM_WAVES = int(os.environ.get('CITW_TEAM_WAVES', 7))
 # instruction estimates used by the balancer (wave 0's fixed work: search + 2-D + 1-D passes; later look-up rounds)
 LOOKUP_PHASES = int(os.environ.get('CITW_TEAM_LOOKUP_COST', 1400))
@@ -70,14 +71,23 @@ SPLIT_IN = int(os.environ.get('CITW_TEAM_SPLIT_INPUTS', 1))           # 1: the h
 FN_SCALE = float(os.environ.get('CITW_TEAM_FN_SCALE', 1.0))            # libm bodies relative to the first estimates in FN
 LIBM_SCALE = float(os.environ.get('CITW_TEAM_LIBM_SCALE', 1.0))        # extra factor for the handed-over cone's libm bodies
 AFFINITY = float(os.environ.get('CITW_TEAM_AFFINITY', 1.0))            # > 0: a sink leans towards the wave that already holds most of its cone
+SPLIT_CHAIN = int(os.environ.get('CITW_TEAM_SPLIT_CHAIN', 0))      # 1: the engine look-up chain (chain round -> second round -> N1 / N2 derivatives) on a wavefront of its own
+ENGINE_WAVE = int(os.environ.get('CITW_TEAM_ENGINE_WAVE', 4))      # ... this one
+CHAIN_COST = float(os.environ.get('CITW_TEAM_CHAIN_COST', 900))    # its look-up passes in balancer units (chain round in front of B1)
+CHAIN_B1 = os.environ.get('CITW_TEAM_CHAIN_B1', 'rc')              # 'rc': barrier B1 behind the chain round; 'r1': behind the second round too
+POST_TASKS = int(os.environ.get('CITW_TEAM_POST_TASKS', 1))        # 1: the glue behind the look-ups as a task graph (fine-grained, values handed over by flags) instead of one cone per derivative
+TASK_MAX = float(os.environ.get('CITW_TEAM_TASK_MAX', 50))         # a task heavier than this (cost units) is split at an inner node
+TASK_MIN = float(os.environ.get('CITW_TEAM_TASK_MIN', 12))         # ... into pieces no lighter than this; lighter shared sub-expressions are recomputed
+TASK_COMM = float(os.environ.get('CITW_TEAM_TASK_COMM', 24))       # cost units between "value stored" and "value usable on another wavefront" (LDS store, flag, poll, load)
 CW = dict(div=11, sqrt=15, sel=3, unord=2, table3=120)
 FN = dict(sc_sin=100, sc_cos=100, sin=100, cos=100, tan=120, exp=40, log10=60, log=60, atan=80, pow=250)
 
 
 class TeamGen(codegen.Gen):
     def __init__(self, variant, waves=None, **kw):
-        super().__init__(variant, **kw)
         self.K = waves or TEAM_WAVES
+        super().__init__(variant, split_chain=bool(SPLIT_CHAIN and self.K > 2), **kw)
+        self.EW = min(ENGINE_WAVE, self.K - 1) if self.chain_round is not None else 0     # the wavefront that walks the later look-up rounds
 
     def closure(self, sinks, within):
         out, st = set(), list(sinks)
@@ -156,6 +166,16 @@ class TeamGen(codegen.Gen):
         load = [sum(cost(m) for m in A0w) + fn_cost(A0w, 0, True) + LOOKUP_PHASES] + [0.0] * (K - 1)
         for q, v in enumerate(PRE_BIAS[:K]):
             load[q] += v
+        if self.chain_round is not None:
+            # the engine wave: cones of the chain round's inputs and of what the second round's inputs need from in front of B1
+            EW = self.EW
+            seeds = [n for n in self.chain_round['ins'] if n in S0]
+            for R in self.rounds[1:]:
+                for n in R['ins']:
+                    seeds += [m for m in self.closure_all(n) if m in S0]
+            AE = self.closure(seeds, S0)
+            load[EW] += sum(cost(m) for m in AE if m not in have[EW]) + CHAIN_COST
+            have[EW] |= AE
         self.h1d = 1 if (OFFLOAD_1D and K > 2 and self.rounds[0]['L1']) else None
         self.l2_helpers = L2_WAVES if (SHARE_2D and K >= 7 and self.h1d is not None and self.rounds[0]['L2']) else []
         if self.h1d is not None:
@@ -237,7 +257,9 @@ class TeamGen(codegen.Gen):
         pcones = {n: self.closure([n], post) for n in psinks}
         phave = [set() for _ in range(K)]
         pins = [set() for _ in range(K)]          # what a wave fetches from LDS behind B1: look-up results, values of other waves
-        pload = [POST_ROUND2_COST if self.nrounds > 1 else 0] + [0] * (K - 1)
+        pload = [0.0] * K
+        if self.nrounds > 1:
+            pload[self.EW] += POST_ROUND2_COST if (self.chain_round is None or CHAIN_B1 == 'rc') else 40.0
         for q, v in enumerate(POST_BIAS[:K]):
             pload[q] += v
         powner = {}
@@ -247,11 +269,17 @@ class TeamGen(codegen.Gen):
             new = [m for m in pcones[n] if m not in phave[b]]
             ins = [c for c in fetched(new) if c not in pins[b] and not (c in have[b] and g.nodes[c][0] not in LOOKUPS)]
             return sum(cost(m) for m in new) + IMPORT_COST * len(ins), ins
-        for n in sorted(psinks, key=lambda n: (-sum(cost(m) for m in pcones[n]), n)):
-            res = [pload[b] + pcost(n, b)[0] for b in range(K)]
-            b = 0 if self.rnd[n] >= 2 else min(range(K), key=lambda q: (res[q] + simd_extra(q, pload, ACTOR_POST) + AFFINITY_POST * (res[q] - pload[q]) + (0.01 * res[q] if SIMD_PAIRS else 0.0), q))
-            pins[b].update(pcost(n, b)[1])
-            phave[b].update(pcones[n]); pload[b] = res[b]; powner[n] = b
+        self.tasks = None
+        if POST_TASKS and K > 2:
+            self.post = post
+            self.plan_post_tasks(psinks, cost, pload)
+            phave, powner, pload = self.phave, self.powner, self.post_load
+        else:
+            for n in sorted(psinks, key=lambda n: (-sum(cost(m) for m in pcones[n]), n)):
+                res = [pload[b] + pcost(n, b)[0] for b in range(K)]
+                b = self.EW if self.rnd[n] >= 2 else min(range(K), key=lambda q: (res[q] + simd_extra(q, pload, ACTOR_POST) + AFFINITY_POST * (res[q] - pload[q]) + (0.01 * res[q] if SIMD_PAIRS else 0.0), q))
+                pins[b].update(pcost(n, b)[1])
+                phave[b].update(pcones[n]); pload[b] = res[b]; powner[n] = b
         self.post, self.phave, self.powner, self.post_load = post, phave, powner, pload
         self.post_sinks = [[n for n in psinks if powner[n] == b] for b in range(K)]
         # ---- what crosses between the waves around B1
@@ -263,9 +291,10 @@ class TeamGen(codegen.Gen):
                     if pre_val(c):
                         need[b].add(c)
         for R in self.rounds[1:]:
-            for c in R['ins']:
-                if pre_val(c):
-                    need[0].add(c)
+            for n in R['ins']:
+                for c in [n] + [m for m in self.closure_all(n) if m not in post]:
+                    if pre_val(c) and (c == n or any(u in post for u in users[c])):
+                        need[self.EW].add(c)
         self.exp = [[] for _ in range(K)]
         self.imp = [[] for _ in range(K)]
         self.xslot = {}
@@ -287,6 +316,131 @@ class TeamGen(codegen.Gen):
             return 0
         self.xdot_owner = [out_owner(n) for n in self.xdot]
         self.dw_owner = {k: out_owner(n) for k, n in self.dw_out.items() if g.nodes[n] != ('in', 'DW', k)}
+
+    # ---- the glue behind the look-ups as a task graph -----------------------------------------------------------------------
+    def plan_post_tasks(self, psinks, cost, pload0):
+        """The derivative cones behind the first look-up round overlap heavily (p-dot and r-dot share 79 of their 83 nodes, the
+        six force / moment derivatives 152 of 281 nodes): one cone per derivative and wavefront computes ~560 nodes for 281
+        distinct ones, and the longest cone (134 nodes on ONE wavefront, latency bound) sets the time between the two barriers.
+        Here the phase is cut into TASKS -- a task = one published value (or one derivative) with the part of its cone that lies
+        above other published values: first at the nodes where the sharing between the derivatives ends, then any task heavier
+        than TASK_MAX at the inner node that halves it -- scheduled over the K wavefronts by list scheduling (longest remaining
+        path first, earliest finish, TASK_COMM units for a value that crosses wavefronts).  A value crosses through LDS (g_y);
+        wave q announces its k-th published value of evaluation SEQ by the release store g_pflag[q] = SEQ * 16 + k, a consumer
+        polls (acquire) once before its first read.  Every wavefront runs its tasks in scheduled order, the schedule is a
+        topological order of the task graph and all wavefronts of the workgroup are resident: a poll cannot dead-lock.  Arithmetic
+        per value is unchanged (same expression trees): results are bit-identical."""
+        g, K, post = self.g, self.K, self.post
+        users = self.users
+        LK = LEAF + LOOKUPS
+        inner = lambda m: m in post and g.nodes[m][0] not in LK
+        r2 = set(n for n in post if self.rnd[n] >= 2)            # needs a later look-up round: stays on wave 0, never published
+        roots = list(psinks)
+
+        def residual(t, cuts):
+            out, st = set(), [t]
+            while st:
+                m = st.pop()
+                if m in out or not inner(m):
+                    continue
+                if m != t and m in cuts:
+                    continue
+                out.add(m)
+                st.extend(build_dag.children(g, m))
+            return out
+        # 1. where the sharing between the derivative cones ends
+        member = collections.defaultdict(set)
+        for r in roots:
+            for m in self.closure([r], post):
+                member[m].add(r)
+        cuts = set()
+        for m in post:
+            if m in r2 or g.nodes[m][0] in LK or len(member[m]) < 2:
+                continue
+            if any(member[u] != member[m] for u in users[m] if u in post):
+                cuts.add(m)
+        w = lambda nodes: sum(cost(m) for m in nodes)
+        # drop frontier values too light to be worth a hand-over (their consumers recompute them)
+        for m in sorted(cuts, key=lambda m: w(residual(m, cuts))):
+            if w(residual(m, cuts - {m})) < TASK_MIN and m not in roots:
+                cuts.discard(m)
+        # 2. split heavy tasks at the inner node whose own cone is closest to half of the task
+        for _ in range(200):
+            tasks = list(dict.fromkeys(list(cuts) + roots))
+            res = {t: residual(t, cuts) for t in tasks}
+            heavy = [t for t in tasks if t not in r2 and w(res[t]) > TASK_MAX]
+            if not heavy:
+                break
+            t = max(heavy, key=lambda t: (w(res[t]), t))
+            best, bestd = None, None
+            for m in res[t]:
+                if m == t or m in r2 or g.ty[m] != 'f':
+                    continue
+                sub = residual(m, cuts) & res[t]
+                ws = w(sub)
+                if ws < TASK_MIN or w(res[t]) - ws < TASK_MIN:
+                    continue
+                d = abs(ws - w(res[t]) / 2.0)
+                if bestd is None or (d, m) < (bestd, best):
+                    best, bestd = m, d
+            if best is None:
+                cuts_before = len(cuts)
+                # cannot be split: leave it
+                res[t] = res[t]
+                # mark by a sentinel so that it is not tried again
+                TASKS_UNSPLIT.add(t)
+                if all(h in TASKS_UNSPLIT for h in heavy):
+                    break
+                continue
+            cuts.add(best)
+        tasks = list(dict.fromkeys([t for t in self.order if t in cuts] + roots))
+        res = {t: residual(t, cuts) for t in tasks}
+        deps = {t: sorted(set(c for m in res[t] for c in build_dag.children(g, m) if c in cuts and c != t)) for t in tasks}
+        cons = collections.defaultdict(list)
+        for t in tasks:
+            for d in deps[t]:
+                cons[d].append(t)
+        tcost = {t: w(res[t]) + 2.0 for t in tasks}
+        blevel = {}
+        for t in reversed([t for t in self.order if t in set(tasks)]):
+            blevel[t] = tcost[t] + max([blevel[u] + TASK_COMM for u in cons[t]], default=0.0)
+        # 3. list scheduling
+        free = list(pload0)                                   # wave 0 starts behind its later look-up rounds
+        wave_of, start, finish = {}, {}, {}
+        done = set()
+        pending = set(tasks)
+        while pending:
+            ready = [t for t in pending if all(d in done for d in deps[t])]
+            t = max(ready, key=lambda t: (blevel[t], -t))
+            best = None
+            for b in ([self.EW] if (t in r2 or any(m in r2 for m in res[t])) else range(K)):
+                est = max([free[b]] + [finish[d] + (0.0 if wave_of[d] == b else TASK_COMM) for d in deps[t]])
+                key = (est + tcost[t], b)
+                if best is None or key < best[0]:
+                    best = (key, b, est)
+            _, b, est = best
+            wave_of[t], start[t], finish[t] = b, est, est + tcost[t]
+            free[b] = finish[t]
+            done.add(t); pending.discard(t)
+        self.tasks = tasks
+        self.task_res, self.task_deps, self.task_wave, self.task_start = res, deps, wave_of, start
+        self.task_cuts = cuts
+        self.task_order = [sorted([t for t in tasks if wave_of[t] == b], key=lambda t: (start[t], t)) for b in range(K)]
+        # publication index of every value that another wavefront reads
+        self.pub = {}
+        self.yslot = {}
+        for b in range(K):
+            k = 0
+            for t in self.task_order[b]:
+                if any(wave_of[u] != b for u in cons[t]):
+                    k += 1
+                    self.pub[t] = (b, k)
+                    self.yslot[t] = len(self.yslot)
+        assert len(self.yslot) <= 32 and all(k <= 15 for _, k in self.pub.values()), (len(self.yslot), self.pub)
+        self.phave = [set().union(*[res[t] for t in self.task_order[b]]) if self.task_order[b] else set() for b in range(K)]
+        self.powner = {t: wave_of[t] for t in tasks}
+        self.post_load = free
+        self.task_makespan = max(finish.values()) if finish else 0.0
 
     # ---- libm phase for an explicit set of nodes (level-1 libm nodes among `needed`)
     def libm_plan(self, needed):
@@ -330,6 +484,18 @@ class TeamGen(codegen.Gen):
           (K, V, [len(h) for h in self.have]))
         P(' * (the union has %d: the rest is recomputed), behind it: %s; %d values cross through g_x. */' %
           (len(set().union(*self.have)), [len(h) for h in self.phave], len(self.xslot)))
+        if self.chain_round is not None:
+            RC = self.chain_round
+            P('/* engine look-up chain on wave %d: chain round (%d inputs, %d searches, %d 2-D + %d 1-D tables of round 1), then round 2, then the N1 / N2 derivatives; barrier B1 behind %s */'
+              % (self.EW, len(RC['ins']), len(RC['searches']), len(RC['L2']), len(RC['L1']), 'the chain round' if CHAIN_B1 == 'rc' else 'round 2'))
+        # the team's own descriptor tables (the rounds differ from the one-wave kernels' when the engine chain is split off)
+        P('#define CITW_TEAM_TABLES 1')
+        P('enum { citw_%s_team_ROUNDS = %d };' % (V, len(self.all_rounds)))
+        for line in self.table_lines('citw_%s_team' % V):
+            P(line)
+        if self.tasks is not None:
+            P('/* glue behind the look-ups: %d tasks, %d values handed over by flags; per wave %s; nodes computed %d for %d distinct */' %
+              (len(self.tasks), len(self.yslot), [len(o) for o in self.task_order], sum(len(h) for h in self.phave), len(set().union(*self.phave))))
         P('enum { citw_%s_team_WAVES = %d, citw_%s_team_NX = %d, citw_%s_team_BARRIERS = 2 };   /* workgroup barriers per evaluation and wavefront */' % (V, K, V, len(self.xslot), V))
 
         def function(b):
@@ -471,13 +637,15 @@ class TeamGen(codegen.Gen):
                 emitted.add(n)
 
             def lookup_round(r, R, allowed):
-                B('  /* ---- look-up round %d */' % (r + 1))
-                mine = [(k, n) for k, n in enumerate(R['ins']) if r > 0 or self.in_owner[n] == 0]
+                # r == 0: the main round on wave 0; 'c': the chain round, 1 ..: later rounds (on the engine wave)
+                B('  /* ---- look-up round %s */' % ('1' if r == 0 else ('chain (engine tables of round 1)' if r == 'c' else str(r + 1))))
+                row = 'wv' if b == 0 else '0'           # (text substitution below: wave 0's own row IS row 0 of the shared blackboards)
+                mine = [(k, n) for k, n in enumerate(R['ins']) if r != 0 or self.in_owner[n] == 0]
                 for k, n in mine:
                     emit_node(n, allowed)
                 B('  if (lane == 0) {')
                 for k, n in mine:
-                    B('    g_in[wv][%d] = %s;' % (k, self.ref(n)))
+                    B('    g_in[%s][%d] = %s;' % (row, R['ibase'] + k, self.ref(n)))
                 B('  }')
                 if r == 0:
                     B('  %s;' % TM(5))
@@ -490,18 +658,33 @@ class TeamGen(codegen.Gen):
                             B('  citw_flag_wait(%d, %s);   /* the input(s) wave %d computes are in g_in[0] */' % (self.P, SEQ, self.P))
                             waited.add(self.P)
                         B('  %s;' % TM(9))
+                sa = (R['maxn'], len(R['searches']), R['sbase'])
+                B('#if CITW_GROUP_LANES == 64 && CITW_FUSED_LOOKUP   /* one episode per team: the look-up lanes verify the hints of their own index searches, no search pass */')
+                if r == 0 and self.h1d is not None:
+                    B('  citw_iflag_raise(0, %s);   /* the look-up inputs are in g_in[0]: wave %d runs the 1-D pass beside the 2-D pass */' % (SEQ, self.h1d))
+                if r == 0:
+                    B('  %s;' % TM(6))
+                if R['L2']:
+                    B('  citw_lookup2d_fused<%d, %d, %d, %d>(%s, S[%d], L[%d][0], g_out%d, lane);' % ((len(R['L2']),) + sa + (row, R['tidx'], R['tidx'], R['oarr'])))
+                if r == 0:
+                    B('  %s;' % TM(7))
+                if R['L1'] and not (r == 0 and self.h1d is not None):
+                    B('  citw_lookup1d_fused<%d, %d, %d, %d>(%s, S[%d], L[%d][1], g_out%d, lane);' % ((len(R['L1']),) + sa + (row, R['tidx'], R['tidx'], R['oarr'])))
+                if r == 0:
+                    B('  %s;' % TM(8))
+                B('#else')
                 if r == 0 and self.l2_helpers and SHARE_SEARCH:
                     ns = len(R['searches'])
                     B('#if CITW_SEARCH_SHARE(%d) > 1   /* several episodes per team: the search passes are shared with waves 2 (and 4) */' % ns)
                     B('  citw_iflag_raise(7, %s);   /* the look-up inputs are in g_in[0] */' % SEQ)
-                    B('  citw_search_part<%d, %d, 0, CITW_SEARCH_SHARE(%d), %d>(wv, S[%d], lane);' % (R['maxn'], ns, ns, R['sbase'], r))
+                    B('  citw_search_part<%d, %d, 0, CITW_SEARCH_SHARE(%d), %d>(wv, S[%d], lane);' % (R['maxn'], ns, ns, R['sbase'], R['tidx']))
                     B('  citw_iflag_raise(0, %s);' % SEQ)
                     B('  citw_iflag_wait(%d, %s);' % (SEARCH_WAVES[0], SEQ))
                     B('#if CITW_SEARCH_SHARE(%d) > 2' % ns)
                     B('  citw_iflag_wait(%d, %s);' % (SEARCH_WAVES[1], SEQ))
                     B('#endif')
                     B('#else')
-                B('  citw_search<%d, %d, %d>(wv, S[%d], lane);' % (R['maxn'], len(R['searches']), R['sbase'], r))
+                B('  citw_search<%d, %d, %d>(%s, S[%d], lane);' % (R['maxn'], len(R['searches']), R['sbase'], row, R['tidx']))
                 if r == 0 and self.h1d is not None:
                     B('  citw_iflag_raise(0, %s);   /* interval indices are in g_sidx[0]: wave %d runs the 1-D pass beside the 2-D pass */' % (SEQ, self.h1d))
                 if r == 0 and self.l2_helpers and SHARE_SEARCH:
@@ -509,15 +692,16 @@ class TeamGen(codegen.Gen):
                 if r == 0:
                     B('  %s;' % TM(6))
                 if R['L2'] and r == 0 and self.l2_helpers:
-                    B('  citw_lookup2d_part<%d, 0, CITW_L2_SHARE>(wv, L[%d][0], g_out%d, lane);   /* (lane groups: waves %s take the other passes) */' % (len(R['L2']), r, r, self.l2_helpers))
+                    B('  citw_lookup2d_part<%d, 0, CITW_L2_SHARE>(wv, L[%d][0], g_out%d, lane);   /* (lane groups: waves %s take the other passes) */' % (len(R['L2']), R['tidx'], R['oarr'], self.l2_helpers))
                 elif R['L2']:
-                    B('  citw_lookup2d<%d>(wv, L[%d][0], g_out%d, lane);' % (len(R['L2']), r, r))
+                    B('  citw_lookup2d<%d>(%s, L[%d][0], g_out%d, lane);' % (len(R['L2']), row, R['tidx'], R['oarr']))
                 if r == 0:
                     B('  %s;' % TM(7))
                 if R['L1'] and not (r == 0 and self.h1d is not None):
-                    B('  citw_lookup1d<%d>(wv, L[%d][1], g_out%d, lane);' % (len(R['L1']), r, r))
+                    B('  citw_lookup1d<%d>(%s, L[%d][1], g_out%d, lane);' % (len(R['L1']), row, R['tidx'], R['oarr']))
                 if r == 0:
                     B('  %s;' % TM(8))
+                B('#endif')
 
             B('static __device__ CITW_EVAL_INLINE double citw_%s_team_eval_w%d(const int stage, const double T, const unsigned TICK)' % (V, b))
             B('{')
@@ -530,7 +714,9 @@ class TeamGen(codegen.Gen):
             mine, st, seen = set(), list(self.pre_sinks[b]) + list(self.post_sinks[b]) + list(self.have[b]), set()
             st += [self.dw_out[k] for k, o in self.dw_owner.items() if o == b]
             if b == 0:
-                st += [n for R in self.rounds for n in R['ins']]
+                st += [n for n in self.rounds[0]['ins']]
+            if b == self.EW:
+                st += [n for R in self.rounds[1:] + ([self.chain_round] if self.chain_round else []) for n in R['ins']]
             imported = set(self.imp[b])
             while st:
                 m = st.pop()
@@ -587,6 +773,17 @@ class TeamGen(codegen.Gen):
             if b == 0:
                 lookup_round(0, self.rounds[0], None)
                 done_rounds.add(0)
+            if self.chain_round is not None and b == self.EW:
+                # the engine chain: its tables of round 1 now, on this wavefront's own (LDS operations of ONE wavefront complete in
+                # order, so the later rounds may read these results without waiting for B1)
+                lookup_round('c', self.chain_round, None)
+                chain_done = True
+                if CHAIN_B1 == 'r1':
+                    done_rounds.add(0)
+                    for r in range(1, self.nrounds):
+                        lookup_round(r, self.rounds[r], None)
+                        done_rounds.add(r)
+                    done_rounds.discard(0)
             def emit_search_share(bb):
                 kq = SEARCH_WAVES.index(bb) + 1
                 nsq = len(self.rounds[0]['searches'])
@@ -649,12 +846,18 @@ class TeamGen(codegen.Gen):
                 B('#endif')
             if b != 0 and b == self.h1d:
                 B('  /* ---- the 1-D interpolation pass of round 1, taken over from wave 0 */')
+                R0_ = self.rounds[0]
+                B('#if CITW_GROUP_LANES == 64 && CITW_FUSED_LOOKUP')
+                B('  citw_iflag_wait(0, %s);   /* the look-up inputs are in g_in[0] */' % SEQ)
+                B('  citw_lookup1d_fused<%d, %d, %d, %d>(0, S[%d], L[%d][1], g_out0, lane);' % (len(R0_['L1']), R0_['maxn'], len(R0_['searches']), R0_['sbase'], R0_['tidx'], R0_['tidx']))
+                B('#else')
                 wait_searches(b)
                 if self.l2_helpers and SHARE_1D:
                     n1 = len(self.rounds[0]['L1'])
                     B('  citw_lookup1d_part<%d, 0, CITW_L1_SHARE(%d)>(0, L[0][1], g_out0, lane);   /* (16 lanes per episode: wave 3 takes the second pass) */' % (n1, n1))
                 else:
                     B('  citw_lookup1d<%d>(0, L[0][1], g_out0, lane);' % len(self.rounds[0]['L1']))
+                B('#endif')
             B('  %s;' % TM(0))
             B('  __syncthreads();   /* B1: look-up results (g_out0) and exchanged values (g_x) are visible to every wave */')
             after_b1[0] = True
@@ -662,19 +865,42 @@ class TeamGen(codegen.Gen):
             done_rounds.add(0)
             for n in self.imp[b]:
                 import_value(n)
-            mine_post = self.phave[b] | (set(n for R in self.rounds[1:] for n in R['ins']) if b == 0 else set())
-            for e in self.rounds[0]['L2'] + self.rounds[0]['L1']:
-                if any(u in mine_post for u in self.users[e['node']]):
+            mine_post = self.phave[b] | (set(n for R in self.rounds[1:] for n in R['ins']) if b == self.EW else set())
+            for e in self.rounds[0]['L2'] + self.rounds[0]['L1'] + (self.chain_round['L2'] + self.chain_round['L1'] if self.chain_round else []):
+                if e['node'] not in emitted and any(u in mine_post for u in self.users[e['node']]):
                     emitted.add(e['node'])
                     B(self.stmt(e['node']))
-            if b == 0:
+            if b == self.EW:
                 for r in range(1, self.nrounds):
-                    lookup_round(r, self.rounds[r], None)
+                    if not (self.chain_round is not None and CHAIN_B1 == 'r1'):
+                        lookup_round(r, self.rounds[r], None)
                     done_rounds.add(r)
                     for e in self.rounds[r]['L2'] + self.rounds[r]['L1']:
-                        emitted.add(e['node'])
-                        B(self.stmt(e['node']))
-            if self.post_sinks[b]:
+                        if e['node'] not in emitted:
+                            emitted.add(e['node'])
+                            B(self.stmt(e['node']))
+            if self.tasks is not None and self.task_order[b]:
+                B('  /* ---- tasks of this wave in the glue behind the look-ups (values of other waves: g_y, announced by g_pflag) */')
+                pwaited = {}
+                for t in self.task_order[b]:
+                    for d in self.task_deps[t]:
+                        if d in emitted:
+                            continue
+                        assert self.task_wave[d] != b and d in self.pub, (t, d)
+                        q, k = self.pub[d]
+                        if pwaited.get(q, 0) < k:
+                            B('  citw_pflag_wait(%d, (%s) * 16u + %du);' % (q, SEQ, k))
+                            pwaited[q] = k
+                        if g.ty[d] == 'b':
+                            B('  const bool b%d = g_y[%d] != 0.0;' % (d, self.yslot[d]))
+                        else:
+                            B('  const double v%d = g_y[%d];' % (d, self.yslot[d]))
+                        emitted.add(d)
+                    emit_node(t)
+                    if t in self.pub:
+                        B('  if (lane == 0) g_y[%d] = %s;' % (self.yslot[t], ('%s ? 1.0 : 0.0' % self.ref(t)) if g.ty[t] == 'b' else self.ref(t)))
+                        B('  citw_pflag_raise(%d, (%s) * 16u + %du);' % (b, SEQ, self.pub[t][1]))
+            elif self.post_sinks[b]:
                 B('  /* ---- share of this wave in the glue behind the look-ups */')
                 for n in self.post_sinks[b]:
                     emit_node(n)
@@ -709,6 +935,7 @@ class TeamGen(codegen.Gen):
             text = re.sub(r'\b(g_xs|g_out0|g_out1|g_in|g_dw|g_cmd|g_f)\[0\]', r'\1[CITW_TROW]', text)
             text = re.sub(r'\bg_m\[(\d+)\]', r'g_m[CITW_MROW(\1)]', text)
             text = re.sub(r'\bg_x\[(\d+)\]', r'g_x[CITW_XOFF + \1]', text)
+            text = re.sub(r'\bg_y\[(\d+)\]', r'g_y[CITW_YOFF + \1]', text)
             text = re.sub(r'\b(citw_search<[^>]*>|citw_search_part<[^>]*>|citw_lookup2d<\d+>|citw_lookup2d_part<[^>]*>|citw_lookup1d<\d+>|citw_lookup1d_part<[^>]*>)\(0, ', r'\1(CITW_TROW, ', text)
             text = text.replace('const int lane = threadIdx.x & 63;', 'const int lane = CITW_LANE;')
             return text
