@@ -330,7 +330,7 @@ class Gen:
         name = R(n)
         if n in self.libm_slot:
             return '  %s %s = g_m[wv][%d];' % (ty, name, self.libm_slot[n])
-        if op == 'div' and CONST_DIV and g.nodes[t[2]][0] == 'cf' and self.const_div_ok(g.nodes[t[2]][1]):
+        if op == 'div' and CONST_DIV and getattr(self, 'const_div', True) and g.nodes[t[2]][0] == 'cf' and self.const_div_ok(g.nodes[t[2]][1]):
             # division by a literal: multiply by the correctly rounded reciprocal + one fma correction step, correctly
             # rounded for every dividend (tools/dag/constdiv.py proves it per divisor); 4 instructions instead of 13
             c = b2f(g.nodes[t[2]][1])
