@@ -24,6 +24,8 @@ struct RolloutArgs {
   int32_t block;                      // threads per workgroup (64 x wavefronts sharing one LDS table copy)
   unsigned long long *prof;           // optional [4] cycle counters of wave 0 / block 0: actor, dynamics, env, steps
   int32_t e0, e_end;                  // team kernels: the episodes [e0, e_end) of the descriptor this launch runs (serl_rollout splits large launches)
+  int32_t *queue;                     // multi-episode team kernels: device counter of the episodes handed out beyond the first one of every lane group
+  int32_t q0;                         // ... the first episode of the queue (episodes [q0, e_end) are taken as lane groups finish theirs)
 };
 
 #define DET_FN __device__ __forceinline__
@@ -163,6 +165,18 @@ struct SerlBarrierCredit {
   {
     const int target = per_step * (piece + 1) / n;
     while (done < target) { __builtin_amdgcn_s_barrier(); ++done; }
+  }
+};
+
+// ... the same for one of several forward passes of a step (multi-episode teams with actors that run one episode at a time):
+// the pass pays the barriers (lo, hi] of the step
+struct SerlBarrierCreditPart {
+  SerlBarrierCredit &base;
+  int lo, hi;
+  __device__ __forceinline__ void operator()(int piece, int n)
+  {
+    const int target = lo + (hi - lo) * (piece + 1) / n;
+    while (base.done < target) { __builtin_amdgcn_s_barrier(); ++base.done; }
   }
 };
 

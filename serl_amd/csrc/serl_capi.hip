@@ -49,12 +49,15 @@ static void serl_launch_rollout_half(int code, const RolloutArgs &a, int grid, h
 
 // two / four episodes per team (rollout_team_half.inc): between CUs and 4 x CUs episodes
 #define SERL_DECL_TEAMG(v) void serl_launch_rollout_team2_##v(const RolloutArgs &a, int grid, hipStream_t stream); \
+                           void serl_launch_rollout_team2s_##v(const RolloutArgs &a, int grid, hipStream_t stream); \
                            void serl_launch_rollout_team4_##v(const RolloutArgs &a, int grid, hipStream_t stream);
 SERL_DECL_TEAMG(nominal) SERL_DECL_TEAMG(ice) SERL_DECL_TEAMG(cg_timed) SERL_DECL_TEAMG(gust) SERL_DECL_TEAMG(test)
 
 static void serl_launch_rollout_teamg(int code, int groups, const RolloutArgs &a, int grid, hipStream_t stream)
 {
-#define SERL_TEAMG_CASE(v) (groups == 4 ? serl_launch_rollout_team4_##v(a, grid, stream) : serl_launch_rollout_team2_##v(a, grid, stream))
+  // (two per team with a streamed actor -- hidden != 32 -- is a kernel of its own: six team wavefronts + two actor wavefronts)
+#define SERL_TEAMG_CASE(v) (groups == 4 ? serl_launch_rollout_team4_##v(a, grid, stream) : \
+                            (a.d.hidden != 32 ? serl_launch_rollout_team2s_##v(a, grid, stream) : serl_launch_rollout_team2_##v(a, grid, stream)))
   switch (code) {
     case SERL_DYN_NOMINAL: SERL_TEAMG_CASE(nominal); break;
     case SERL_DYN_ICE: SERL_TEAMG_CASE(ice); break;
@@ -72,7 +75,14 @@ static void serl_launch_rollout_teamg(int code, int groups, const RolloutArgs &a
 // H = 32 only.  kernel_hint SERL_KERNEL_TEAM2 / TEAM4 force it.
 static int serl_use_teamg(const serl_ctx *c, const serl_rollout_desc *d, int hint, int episodes)
 {
-  if (d->hidden != 32) return 0;
+  if (d->hidden != 32) {
+    // actors without one hidden row per lane (SERL10's 72, the TD3 actor's 96): the actor wavefront runs the episodes' forward
+    // passes one after the other -- two per team (~33 us per env step for the pair, actor-bound) beat one wavefront per episode
+    // (57 - 61 us) while every pair has a CU: CUs < episodes <= 2 x CUs; four per team would be slower than four lone wavefronts
+    if (hint == SERL_KERNEL_TEAM2) return 2;
+    if (hint != SERL_KERNEL_AUTO) return 0;
+    return (episodes > c->num_cus && episodes <= 2 * c->num_cus) ? 2 : 0;
+  }
   if (hint == SERL_KERNEL_TEAM2) return 2;
   if (hint == SERL_KERNEL_TEAM4) return 4;
   if (hint != SERL_KERNEL_AUTO) return 0;
@@ -280,6 +290,7 @@ int serl_ctx_create(int device, serl_ctx **out)
   }
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
+  HIP_TRY(hipMalloc((void **)&c->queue, SERL_MAX_SLOTS * sizeof(int32_t)));
   *out = c;
   return SERL_OK;
 }
@@ -292,6 +303,7 @@ int serl_ctx_destroy(serl_ctx *c)
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->prof) (void)hipFree(c->prof);
+  if (c->queue) (void)hipFree(c->queue);
   delete c;
   return SERL_OK;
 }
@@ -344,8 +356,8 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   if (d->max_steps <= 0) return fail(SERL_E_INVALID, "serl_rollout: max_steps");
   if (d->kernel_hint < SERL_KERNEL_AUTO || d->kernel_hint > SERL_KERNEL_TEAM4) return fail(SERL_E_INVALID, "serl_rollout: kernel_hint");
   const int hint = d->lanes_per_wave > 0 ? SERL_KERNEL_AUTO : serl_resolve_hint(c, d->kernel_hint);
-  if (d->hidden != 32 && (hint == SERL_KERNEL_TEAM2 || hint == SERL_KERNEL_TEAM4 || hint == SERL_KERNEL_HALF))
-    return fail(SERL_E_UNSUPPORTED, "serl_rollout: the multi-episode kernels (kernel_hint TEAM2 / TEAM4 / HALF) exist for hidden = 32 only");
+  if (d->hidden != 32 && (hint == SERL_KERNEL_TEAM4 || hint == SERL_KERNEL_HALF))
+    return fail(SERL_E_UNSUPPORTED, "serl_rollout: kernel_hint TEAM4 / HALF needs hidden = 32 (other shapes: TEAM2, the actor wavefront runs the two episodes one after the other)");
   HIP_TRY(hipSetDevice(c->device));
   const BuildSlot &s = c->slots[d->build_slot];
   hipStream_t stream = (hipStream_t)stream_;
@@ -409,7 +421,17 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     a.lanes = 1;
     a.block = 512;
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
-    serl_launch_rollout_teamg(s.code, teamg, a, (d->n_episodes + teamg - 1) / teamg, stream);
+    // at most one team per CU; the episodes without a lane group at the start wait in the work queue (rollout_team_half.inc)
+    int grid = (d->n_episodes + teamg - 1) / teamg;
+    if (grid > c->num_cus && d->concurrent_episodes <= 0) {
+      grid = c->num_cus;
+      a.queue = c->queue + d->build_slot;
+      a.q0 = grid * teamg;
+      HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(int32_t), stream));
+    } else {
+      a.queue = nullptr; a.q0 = d->n_episodes;
+    }
+    serl_launch_rollout_teamg(s.code, teamg, a, grid, stream);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = timed;
@@ -418,20 +440,20 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   if (lanes <= 0 && serl_has_wave_kernel(s.code) && serl_use_team_rounds(c, d, hint, together)) {
     // more than 4 x CUs episodes, alone on the GPU: rounds of 4 x CUs episodes (four per team, every CU busy), then the rest
     // with whichever team kernel suits its count -- 4 x CUs + 2 episodes cost 30.8 + 21.6 us per env step, not 62.9
+    // ONE launch: a team of four lane groups per CU, the other episodes in the work queue (rollout_team_half.inc) -- a lane group
+    // takes the next episode when its own ends, so episodes of different lengths (training: untrained actors crash within
+    // seconds) keep every lane group busy instead of rounds that each wait for their longest episode.  (Round 2 ran rounds of
+    // 4 x CUs episodes; with equal-length episodes the tail of a queue run costs the four-per-team step where a round of its own
+    // could use the two-per-team kernel: 1 536 x 8 001 steps 7 % slower, any mix of lengths faster.)
     a.lanes = 1;
     a.block = 512;
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
-    const int full = 4 * c->num_cus;
-    for (int e0 = 0; e0 < d->n_episodes; e0 += full) {
-      const int n = d->n_episodes - e0 < full ? d->n_episodes - e0 : full;
-      a.e0 = e0; a.e_end = e0 + n;
-      if (n <= c->num_cus) serl_launch_rollout_team(s.code, a, n, stream);
-      else {
-        const int g = n <= 2 * c->num_cus ? 2 : 4;
-        serl_launch_rollout_teamg(s.code, g, a, (n + g - 1) / g, stream);
-      }
-      HIP_TRY(hipGetLastError());
-    }
+    a.e0 = 0; a.e_end = d->n_episodes;
+    a.queue = c->queue + d->build_slot;
+    a.q0 = 4 * c->num_cus;
+    HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(int32_t), stream));
+    serl_launch_rollout_teamg(s.code, 4, a, c->num_cus, stream);
+    HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = timed;
     return SERL_OK;

@@ -34,4 +34,5 @@ struct serl_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   unsigned long long *prof = nullptr;   // device [32], allocated when SERL_PROFILE=1
+  int32_t *queue = nullptr;             // device [SERL_MAX_SLOTS]: work-queue counters of the multi-episode team kernels, one per build slot
 };

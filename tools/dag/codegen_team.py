@@ -476,7 +476,10 @@ class TeamGen(codegen.Gen):
                     self.row_slot[node] = (q, 2 * jl + (0 if which == 'r0' else 1))
         shared = self.shared_libm
         # does anybody but the owner read a wave's libm results in front of B1?  (then the owner raises its flag)
-        SEQ = 'TICK * 8u + (unsigned)stage + 1u'
+        # sequence number of the evaluation for the hand-over flags: FSEQ counts the team's env steps (NOT the model clock TICK: the
+        # lane groups of a multi-episode team carry episodes with different clocks, and a lane group that takes a new episode from
+        # the work queue starts its clock again)
+        SEQ = 'FSEQ * 8u + (unsigned)stage + 1u'
         out = []
         P = out.append
         P('/* GENERATED by tools/dag/codegen_team.py from gen/citation_%s.inc -- do not edit.' % V)
@@ -703,7 +706,7 @@ class TeamGen(codegen.Gen):
                     B('  %s;' % TM(8))
                 B('#endif')
 
-            B('static __device__ CITW_EVAL_INLINE double citw_%s_team_eval_w%d(const int stage, const double T, const unsigned TICK)' % (V, b))
+            B('static __device__ CITW_EVAL_INLINE double citw_%s_team_eval_w%d(const int stage, const double T, const unsigned TICK, const unsigned FSEQ)' % (V, b))
             B('{')
             B('  const CitwSearch (*S)[64] = g_S; const CitwLookup (*L)[2][64] = g_L;')
             B('  const bool major = stage == 0;')
@@ -943,11 +946,11 @@ class TeamGen(codegen.Gen):
         for b in range(K - 1, -1, -1):
             P(function(b))
         P('/* wave-uniform dispatch: each wavefront of the team executes exactly one of the parts and its two barriers */')
-        P('static __device__ __forceinline__ double citw_%s_team_eval(const int wave, const int stage, const double T, const unsigned TICK)' % V)
+        P('static __device__ __forceinline__ double citw_%s_team_eval(const int wave, const int stage, const double T, const unsigned TICK, const unsigned FSEQ)' % V)
         P('{')
         for b in range(K - 1):
-            P('  if (wave == %d) return citw_%s_team_eval_w%d(stage, T, TICK);' % (b, V, b))
-        P('  return citw_%s_team_eval_w%d(stage, T, TICK);' % (V, K - 1))
+            P('  if (wave == %d) return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ);' % (b, V, b))
+        P('  return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ);' % (V, K - 1))
         P('}')
         ks = sorted(self.kslot.items(), key=lambda kv: kv[1])
         if ks:
@@ -960,8 +963,9 @@ class TeamGen(codegen.Gen):
 
 def main():
     variants = [a for a in sys.argv[1:] if not a.startswith('--')] or ['nominal']
+    waves = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--waves=')), None)     # --waves=6 --suffix=6: the six-wavefront team of the streamed-actor kernels (gen/citation_<v>_team6.inc)
     for v in variants:
-        gen = TeamGen(v, hoist='--hoist-invariants' in sys.argv, lds_consts=int(os.environ.get('CITW_TEAM_LDS_CONSTS', 0)))
+        gen = TeamGen(v, waves=waves, hoist='--hoist-invariants' in sys.argv, lds_consts=int(os.environ.get('CITW_TEAM_LDS_CONSTS', 0)))
         text = gen.emit_team()
         suffix = next((a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--suffix=')), '')     # experiments: --suffix=_exp7
         path = os.path.join(build_dag.ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_team%s.inc' % (v, suffix))
