@@ -54,7 +54,9 @@ def make_population(pop, rank, seed=7, tag='serl50'):
 def cpu_port(w, hidden, ref, moe, faults_of=None, build_of=None):
     """The C restatement (oracle/rollout_ref.c) on all host cores, the same workload (the whole evaluation once)."""
     from oracle import rollout as R
-    cores = os.cpu_count() or 1
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'tools'))
+    from time_reference import host_cores
+    cores = host_cores()              # (affinity mask capped by the cgroup CPU quota: the GPU box shows 256 logical CPUs, 16 cores' worth usable)
     net = dict(state_dim=7, action_dim=3, hidden=hidden, num_layers=3, activation='tanh')
     E = len(moe)
     R.rollout(w, net, moe[:cores], ref[:cores], t_max=80.0, threads=cores)       # warm-up (page-in, lib build)
@@ -84,12 +86,12 @@ def cpu_baseline(w, hidden, ref, moe, faults_of=None, build_of=None):
     cb = None
     if refso.available():
         try:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'tools', 'time_reference.py'), '--episodes', '1'],
+            r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'tools', 'time_reference.py'), '--episodes', '2'],
                                capture_output=True, text=True, timeout=900)
             m = json.loads(r.stdout.strip().splitlines()[-1])
             cb = dict(value=m['env_steps_per_s'], unit='env-steps/s', cores=m['procs'], kind='reference-python',
                       per_core=m['env_steps_per_s_per_core'], reference=m['reference'],
-                      sample='%d processes (one per host core) x %d full 80 s episode(s) = %d env steps of the reference\'s unmodified '
+                      sample='%d processes (one per usable host core) x %d full 80 s episode(s) = %d env steps of the reference\'s unmodified '
                              'Agent.evaluate (SERL50 actors, base reference, nominal build) after a 5 s warm-up episode each, %.1f s wall '
                              '(+ %.0f s process start-up, untimed)' % (m['procs'], m['episodes_per_proc'], m['env_steps'], m['seconds'], m['startup_seconds']),
                       port=port)

@@ -37,6 +37,8 @@ class GenerationResult:
     pop: PopResult                    # the GA evaluate loop (agent.py:229-256)
     rl_episode: Optional[Episode]     # the RL actor's exploration episode (agent.py:269), None without an RL actor
     kernel_ms: float
+    stored: Optional[list] = None     # (_defer_store) [(agent, episode index, steps, cost steps)] of the episodes to store
+    staged: Optional[torch.Tensor] = None   # (_defer_store) the staged transition rows [episodes, T, 20]
 
 
 def store_transitions(rows, agent, replay_buffer=None, counters=None, engine=None):
@@ -69,7 +71,7 @@ def _episode(out, e, ref_row, smooth, smooth_fitness):
 
 def evaluate_generation(pop: Sequence, rl_agent=None, *, args, mode='nominal', t_max=20, refs=None, rl_noise=None,
                         engine: Optional[RolloutEngine] = None, replay_buffer=None, counters=None,
-                        store: bool = True) -> GenerationResult:
+                        store: bool = True, env_config=0, incremental=False, _defer_store: bool = False) -> GenerationResult:
     """Steps (1) and (4) of a generation in one launch.
 
     pop      : GeneticAgent / Actor sequence (one network shape); rl_agent: the RL learner's agent or None
@@ -77,7 +79,11 @@ def evaluate_generation(pop: Sequence, rl_agent=None, *, args, mode='nominal', t
     refs     : f64 [pop*num_evals (+1), T, 3] / [T, 3] radians (refsignals.tabulate), or refsignals.ref_specs rows
                [pop*num_evals (+1)] / [1] (generated in the kernel); None = base reference
     rl_noise : f64 [T, 3] clipped exploration noise; None = drawn here as agent.py:90-93 would
-    store    : append the transitions of every member's last evaluation and of the RL episode to the buffers"""
+    store    : append the transitions of every member's last evaluation and of the RL episode to the buffers
+    env_config / incremental : builds.env_config(name) for the other env configurations (the attitude task by default; the
+               device replay rings hold the attitude task's rows only: use list-backed buffers with the others)
+    _defer_store : (evaluate_generation_sharded) stage the transitions but leave the buffers alone; the list of stored
+               episodes and the staged rows come back as result.stored / result.staged"""
     engine = engine or default_engine()
     ne = int(args.num_evals)
     actors = [_actor_of(a) for a in pop]
@@ -117,7 +123,7 @@ def evaluate_generation(pop: Sequence, rl_agent=None, *, args, mode='nominal', t
     build, row = builds.resolve_mode(mode)
     faults = None if row == builds.NOMINAL_ROW else [row] * Etot
     out = engine.rollout(pack_population(members), spec, moe, refs, build=build, faults=faults, action_noise=noise,
-                         noise_row=noise_row, t_max=t_max, traces=True, transitions=store)
+                         noise_row=noise_row, t_max=t_max, traces=True, transitions=store, env_config=env_config, incremental=incremental)
     ls = out['length_steps'].cpu().numpy()
     sm = metrics.calc_smoothness(out['actions'], np.abs(ls)).cpu().numpy()
     ret = out['fitness'].cpu().numpy()
@@ -147,10 +153,74 @@ def evaluate_generation(pop: Sequence, rl_agent=None, *, args, mode='nominal', t
         rl_ep = _episode(out, e, ref_row, sm[e], smooth_fitness)
         if store:
             stored.append((rl_agent, e, abs(int(ls[e])), int(cs[e])))
-    if stored:
+    if stored and not _defer_store:
         from . import replay
-        replay.store_episodes(engine, out['transitions'], stored, replay_buffer, counters)
-    return GenerationResult(pop=res, rl_episode=rl_ep, kernel_ms=engine.last_kernel_ms)
+        replay.store_episodes(engine, out['transitions'], stored, replay_buffer, counters, state_dim=spec.state_dim, action_dim=spec.action_dim)
+    g = GenerationResult(pop=res, rl_episode=rl_ep, kernel_ms=engine.last_kernel_ms)
+    if _defer_store:
+        g.stored, g.staged = stored, out.get('transitions')
+    return g
+
+
+def evaluate_generation_sharded(pop: Sequence, rl_agent=None, *, args, mode='nominal', t_max=20, refs=None, rl_noise=None,
+                                engine: Optional[RolloutEngine] = None, replay_buffer=None, counters=None,
+                                store: bool = True) -> GenerationResult:
+    """`evaluate_generation` with the population sharded over the ranks of the default process group (one process per GPU,
+    `torch.distributed` over RCCL): rank r evaluates the contiguous member block `distributed.member_block` gives
+    it, ONE all_gather brings every member's result rows to every rank, ONE more the rows of every member's stored episode
+    (`distributed.gather_stored_episodes`) -- after which every rank appends all `pop` episodes to its buffers in member
+    order, exactly like the single-process path, so the replicated SSNE epoch finds identical replay rings everywhere.
+    The RL actor's exploration episode (agent.py:269) is flown by EVERY rank (same weights, same pre-drawn noise: the host
+    RNG streams are replicated), which keeps its episode and its buffer entries local.  Without a process group (or with one
+    rank) this IS evaluate_generation.  The per-step traces of the population (actions / states / rewards) stay on the rank
+    that flew them: `result.pop.actions` etc. are None here.
+
+    refs: None, one [T, 3] table, or [pop*num_evals (+1), T, 3] for ALL members (every rank passes the same array and uses
+    its block's rows)."""
+    import torch.distributed as dist
+    from . import distributed as sd, replay
+    ws = dist.get_world_size() if dist.is_initialized() else 1
+    if ws == 1:
+        return evaluate_generation(pop, rl_agent, args=args, mode=mode, t_max=t_max, refs=refs, rl_noise=rl_noise, engine=engine,
+                                   replay_buffer=replay_buffer, counters=counters, store=store)
+    engine = engine or default_engine()
+    rk = dist.get_rank()
+    ne, n_pop = int(args.num_evals), len(pop)
+    lo, hi = sd.member_block(n_pop, ws, rk)
+    if rl_agent is not None and rl_noise is None:
+        T_ = refsignals.n_steps_for(t_max)
+        rl_noise = np.clip(args.noise_sd * np.random.randn(T_, 3), -args.noise_clip, args.noise_clip)     # the same draw on every rank
+    local_refs = refs
+    if refs is not None and not (isinstance(refs, np.ndarray) and refs.dtype.names is not None):
+        r_ = torch.as_tensor(refs, dtype=torch.float64)
+        if r_.dim() == 3:
+            rows = list(range(lo * ne, hi * ne)) + ([n_pop * ne] if rl_agent is not None else [])
+            local_refs = r_[rows]
+    g = evaluate_generation(pop[lo:hi], rl_agent, args=args, mode=mode, t_max=t_max, refs=local_refs, rl_noise=rl_noise,
+                            engine=engine, store=store, _defer_store=True)
+    dev = engine.device
+    p = g.pop
+    rows = np.stack([p.fitness, p.returns, p.smoothness, p.length_t, p.length_steps.astype(np.float64), p.cost_steps.astype(np.float64)], -1)
+    allr = sd.gather_rows(torch.as_tensor(rows).to(dev), n_pop, ws, rk, device=dev).cpu().numpy()
+    fitness = allr[..., 0]
+    pf = np.mean(fitness, axis=0)
+    res = PopResult(fitness=fitness, returns=allr[..., 1], smoothness=allr[..., 2], length_steps=allr[..., 4].astype(np.int32),
+                    length_t=allr[..., 3], cost_steps=allr[..., 5].astype(np.int32), pop_fitness=pf, champion=int(np.argmax(pf)),
+                    worst=int(np.argmin(pf)), kernel_ms=p.kernel_ms, episode_member=np.repeat(np.arange(n_pop, dtype=np.int32), ne))
+    if store:
+        n_loc = hi - lo
+        idx = [e for (_, e, _, _) in g.stored[:n_loc]]
+        staged = g.staged[idx] if n_loc else g.staged[:0]
+        steps = [n for (_, _, n, _) in g.stored[:n_loc]]
+        cost = [c for (_, _, _, c) in g.stored[:n_loc]]
+        allb, asteps, acost = sd.gather_stored_episodes(torch.as_tensor(staged).to(dev), steps, cost, n_pop, ws, rk)
+        items = [(pop[m], m, int(asteps[m]), int(acost[m])) for m in range(n_pop)]
+        if rl_agent is not None:
+            a_, e_, n_, c_ = g.stored[-1]
+            allb = torch.cat([allb, torch.as_tensor(g.staged[e_:e_ + 1]).to(allb.device)])
+            items.append((rl_agent, n_pop, n_, c_))
+        replay.store_episodes(engine, allb, items, replay_buffer, counters)
+    return GenerationResult(pop=res, rl_episode=g.rl_episode, kernel_ms=g.kernel_ms)
 
 
 def validate_actor(agent, *, tests=5, mode='nominal', t_max=20, refs=None, smooth_fitness=False,

@@ -153,3 +153,80 @@ def test_bench_starts_itself_for_n_gpus_or_says_why_not():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 1 and line['value'] > 0
+
+
+# ---- a whole generation sharded over two ranks (serl_amd.generation.evaluate_generation_sharded) --------------------------
+class _Buf(list):
+    def add(self, *t):
+        self.append(tuple(np.asarray(x).copy() if hasattr(x, 'shape') else x for x in t))
+
+
+def _gen_setup():
+    import argparse
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import serl_amd
+    from serl_amd.actor import unpack_into
+    from conftest import OracleEngine
+    args = argparse.Namespace(hidden_size=32, num_layers=3, activation_actor='tanh', state_dim=7, action_dim=3,
+                              device=torch.device('cpu'), num_evals=2, smooth_fitness=False, noise_sd=0.2, noise_clip=0.5)
+    rows = np.load(os.path.join(ROOT, 'tests', 'golden', 'actors.npz'))['serl50']
+
+    class Agent:
+        def __init__(self, row):
+            self.actor = serl_amd.Actor(args)
+            unpack_into(self.actor, torch.from_numpy(row[:3715].copy()))
+            self.buffer, self.critical_buffer = _Buf(), _Buf()
+    pop = [Agent(rows[i]) for i in (18, 0, 7, 33, 5)]
+    rl = Agent(rows[9])
+    from serl_amd import refsignals
+    refs = refsignals.synthetic_reference_tables(5 * 2 + 1, 2, 20, seed=3)
+    noise = np.clip(0.2 * np.random.RandomState(5).randn(refs.shape[1], 3), -0.5, 0.5)
+    return serl_amd, args, pop, rl, refs, noise, OracleEngine()
+
+
+def _digest(pop, rl, shared, counters, g):
+    bufs = [shared] + [a.buffer for a in pop + [rl]] + [a.critical_buffer for a in pop + [rl]]
+    return dict(fitness=g.pop.fitness.copy(), lengths=g.pop.length_steps.copy(), champion=g.pop.champion, counters=dict(counters),
+                lens=[len(b) for b in bufs], sums=[float(sum(float(np.sum(t[0])) + float(np.sum(t[1])) + t[3] for t in b)) for b in bufs],
+                rl_fitness=g.rl_episode.fitness)
+
+
+def _gen_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    serl_amd, args, pop, rl, refs, noise, eng = _gen_setup()
+    from serl_amd.generation import evaluate_generation_sharded
+    shared, counters = _Buf(), {}
+    g = evaluate_generation_sharded(pop, rl, args=args, t_max=20, refs=refs, rl_noise=noise, engine=eng, replay_buffer=shared, counters=counters)
+    q.put((rank, _digest(pop, rl, shared, counters, g)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_generation_sharded_over_two_ranks_equals_single_process():
+    """evaluate_generation_sharded on two gloo ranks (population of 5: blocks 3 + 2, the RL actor's exploration episode on
+    both): the gathered fitness table, the champion, the counters and EVERY buffer (shared, per agent, critical) must come out
+    on both ranks exactly as evaluate_generation fills them in one process.  (Local evaluation = the CPU oracle behind
+    RolloutEngine.rollout's call shape: the sharding, the two all-gathers and the buffer order are what is under test.)"""
+    serl_amd, args, pop, rl, refs, noise, eng = _gen_setup()
+    shared, counters = _Buf(), {}
+    g = serl_amd.evaluate_generation(pop, rl, args=args, t_max=20, refs=refs, rl_noise=noise, engine=eng, replay_buffer=shared, counters=counters)
+    single = _digest(pop, rl, shared, counters, g)
+    assert single['lens'][0] == sum(single['lens'][1:7]) and single['counters']['num_episodes'] == 6
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gen_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        np.testing.assert_array_equal(got[r]['fitness'], single['fitness'])
+        np.testing.assert_array_equal(got[r]['lengths'], single['lengths'])
+        assert got[r]['champion'] == single['champion'] and got[r]['counters'] == single['counters']
+        assert got[r]['lens'] == single['lens'] and got[r]['sums'] == single['sums'] and got[r]['rl_fitness'] == single['rl_fitness']

@@ -60,13 +60,25 @@ def worker(rank, episodes, q, go):
     q.put(('done', rank, steps, time.perf_counter() - t0))
 
 
+def host_cores():
+    """CPU cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU box shows 256 logical
+    CPUs to a container that is allowed 16 cores' worth of time: 256 processes there only add start-up time)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            n = max(1, min(n, int(int(q) / int(p) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def measure(procs=None, episodes=1):
     import multiprocessing as mp
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    procs = procs or avail
+    procs = procs or host_cores()
     ctx = mp.get_context('spawn')
     q, go = ctx.Queue(), ctx.Event()
     ps = [ctx.Process(target=worker, args=(r, episodes, q, go)) for r in range(procs)]
@@ -86,7 +98,7 @@ def measure(procs=None, episodes=1):
     return {'what': 'reference Python rollout (unmodified Agent.evaluate + CitationEnv + torch Actor + the shipped _citation '
                     'library via ctypes; PH-LAB nominal, SERL50 actors, 80 s episodes), one process per core, torch 1 thread each',
             'reference': 'archive oracle/_ref' if os.path.isfile(refso.REF) else refso.REF,
-            'procs': procs, 'host_cores': os.cpu_count(), 'episodes_per_proc': episodes, 'env_steps': steps,
+            'procs': procs, 'host_cores': os.cpu_count(), 'usable_cores': host_cores(), 'episodes_per_proc': episodes, 'env_steps': steps,
             'seconds': round(wall, 2), 'startup_seconds': round(t0 - t_spawn, 1), 'env_steps_per_s': round(steps / wall, 1),
             'env_steps_per_s_per_core': round(steps / wall / procs, 1)}
 
