@@ -203,6 +203,14 @@ __shared__ unsigned long long g_tlastw[16];    // ... and for the other waves (b
 #define CITW_U(k) ((void)0)
 #endif
 
+#ifndef CITW_POLL_SLEEP
+#define CITW_POLL_SLEEP 0        // s_sleep argument between two polls of a hand-over flag (0: poll back to back)
+#endif
+#if CITW_POLL_SLEEP > 0
+#define CITW_POLL_PAUSE() __builtin_amdgcn_s_sleep(CITW_POLL_SLEEP)
+#else
+#define CITW_POLL_PAUSE() ((void)0)
+#endif
 // Hand-over of a look-up input from a helper wavefront to wave 0 without a barrier (team kernels): the helper stores the
 // value(s), then the sequence number of the evaluation (release); wave 0 polls the number (acquire) before it reads.
 // All wavefronts of a workgroup are resident, so the poll cannot starve the writer; numbers only grow within an episode.
@@ -216,7 +224,7 @@ static __device__ __forceinline__ void citw_flag_wait(int q, unsigned seq)
   seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);     // (two episodes per team: the first one's model clock counts for both)
   // "reached", not "equal": a producer can never be an evaluation ahead (barrier B2 separates evaluations), but a poll that
   // tolerates it cannot hang either
-  while ((int)(__hip_atomic_load(&g_flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) __builtin_amdgcn_s_sleep(1);
+  while ((int)(__hip_atomic_load(&g_flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) CITW_POLL_PAUSE();
 }
 
 // ... and a second set for the look-up inputs a helper wavefront computes for wave 0 (spread-input partitions)
@@ -228,7 +236,7 @@ static __device__ __forceinline__ void citw_iflag_raise(int q, unsigned seq)
 static __device__ __forceinline__ void citw_iflag_wait(int q, unsigned seq)
 {
   seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);     // (two episodes per team: the first one's model clock counts for both)
-  while ((int)(__hip_atomic_load(&g_iflag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) __builtin_amdgcn_s_sleep(1);
+  while ((int)(__hip_atomic_load(&g_iflag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) CITW_POLL_PAUSE();
 }
 
 // ... and a third for the task graph behind the look-ups (gen/citation_<v>_team.inc): wave q announces its k-th published value
@@ -241,7 +249,7 @@ static __device__ __forceinline__ void citw_pflag_raise(int q, unsigned seq)
 static __device__ __forceinline__ void citw_pflag_wait(int q, unsigned seq)
 {
   seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);
-  while ((int)(__hip_atomic_load(&g_pflag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) __builtin_amdgcn_s_sleep(1);
+  while ((int)(__hip_atomic_load(&g_pflag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) CITW_POLL_PAUSE();
 }
 
 static __device__ __forceinline__ unsigned long long citw_d2u(double d) { return (unsigned long long)__double_as_longlong(d); }
@@ -284,6 +292,9 @@ static __device__ __forceinline__ void citw_search_part(const int wv, const Citw
   for (int base = PART * CITW_GROUP_LANES; base < COUNT; base += NPARTS * CITW_GROUP_LANES) citw_search_pass<MAXN, COUNT, SBASE>(wv, S, lane + base);
 }
 
+#ifndef CITW_FUSED_LATER
+#define CITW_FUSED_LATER 0       // 1: ... in the look-up rounds behind the first one only (two 2-D + two 1-D tables on the chain every wavefront waits for)
+#endif
 #ifndef CITW_SEARCH_HINT
 #define CITW_SEARCH_HINT 1
 #endif

@@ -75,6 +75,7 @@ SPLIT_CHAIN = int(os.environ.get('CITW_TEAM_SPLIT_CHAIN', 0))      # 1: the engi
 ENGINE_WAVE = int(os.environ.get('CITW_TEAM_ENGINE_WAVE', 4))      # ... this one
 CHAIN_COST = float(os.environ.get('CITW_TEAM_CHAIN_COST', 900))    # its look-up passes in balancer units (chain round in front of B1)
 CHAIN_B1 = os.environ.get('CITW_TEAM_CHAIN_B1', 'rc')              # 'rc': barrier B1 behind the chain round; 'r1': behind the second round too
+PRELOAD = int(os.environ.get('CITW_TEAM_PRELOAD', 1))             # 1: every wave loads the states / commands / table constants it reads ONCE, at the top of the evaluation, into locals (a flag poll or a barrier makes the compiler re-load an inline g_xs[..] otherwise)
 POST_TASKS = int(os.environ.get('CITW_TEAM_POST_TASKS', 1))        # 1: the glue behind the look-ups as a task graph (fine-grained, values handed over by flags) instead of one cone per derivative
 TASK_MAX = float(os.environ.get('CITW_TEAM_TASK_MAX', 50))         # a task heavier than this (cost units) is split at an inner node
 TASK_MIN = float(os.environ.get('CITW_TEAM_TASK_MIN', 12))         # ... into pieces no lighter than this; lighter shared sub-expressions are recomputed
@@ -662,7 +663,8 @@ class TeamGen(codegen.Gen):
                             waited.add(self.P)
                         B('  %s;' % TM(9))
                 sa = (R['maxn'], len(R['searches']), R['sbase'])
-                B('#if CITW_GROUP_LANES == 64 && CITW_FUSED_LOOKUP   /* one episode per team: the look-up lanes verify the hints of their own index searches, no search pass */')
+                B('#if CITW_GROUP_LANES == 64 && %s   /* one episode per team: the look-up lanes verify the hints of their own index searches, no search pass */'
+                  % ('CITW_FUSED_LOOKUP' if r == 0 else '(CITW_FUSED_LOOKUP || CITW_FUSED_LATER)'))
                 if r == 0 and self.h1d is not None:
                     B('  citw_iflag_raise(0, %s);   /* the look-up inputs are in g_in[0]: wave %d runs the 1-D pass beside the 2-D pass */' % (SEQ, self.h1d))
                 if r == 0:
@@ -928,6 +930,23 @@ class TeamGen(codegen.Gen):
             B('}')
             self.in_override = {}
             text = '\n'.join(body)
+            if PRELOAD:
+                # states, commands and table constants as locals loaded once at the top (one batch of LDS loads, one wait): an inline
+                # g_xs[..][k] is loaded again behind every flag poll / barrier (memory fences) -- up to ten exposed LDS round trips
+                # per wave and evaluation.  The rows are not written during an evaluation (the ODE5 combination follows it).
+                import re as _re
+                head, rest = text.split('\n', 2)[0:2], text.split('\n', 2)[2]
+                decl = []
+                for arr, pre in (('g_xs', 'xs_'), ('g_cmd', 'cm_')):
+                    ks = sorted({int(k) for k in _re.findall(r'\b%s\[wv\]\[(\d+)\]' % arr, rest)})
+                    for k in ks:
+                        decl.append('  const double %s%d = %s[wv][%d];' % (pre, k, arr, k))
+                    rest = _re.sub(r'\b%s\[wv\]\[(\d+)\]' % arr, lambda m: '%s%s' % (pre, m.group(1)), rest)
+                ks = sorted({int(k) for k in _re.findall(r'\bg_ro\[(\d+)\]', rest)})
+                for k in ks:
+                    decl.append('  const double ro_%d = g_ro[%d];' % (k, k))
+                rest = _re.sub(r'\bg_ro\[(\d+)\]', lambda m: 'ro_%s' % m.group(1), rest)
+                text = '\n'.join(head + decl + [rest])
             # shared blackboards live in row 0; each wave has its own libm / look-up input rows
             text = text.replace('g_in[wv]', 'g_in[%d]' % b).replace('g_m[wv]', 'g_m[%d]' % b)
             text = text.replace('g_inv[wv]', 'g_inv[%d]' % b).replace('g_out%d[wv]' % len(self.rounds), 'g_out%d[%d]' % (len(self.rounds), b))
