@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """Copy the summaries of one `tools/profile_round.sh <tag>` run from gpurun_out/<tag>/ into profiles/<series>_*:
-   python tools/distill_profiles.py r02j r02_j        (also refreshes profiles/pmc_current.json, which bench.py reads)"""
+   python tools/distill_profiles.py r03p r03_a        (also refreshes profiles/pmc_current.json and floors_current.json, which bench.py reads)"""
 import json, shutil, sys
 tag, series = sys.argv[1], sys.argv[2]
 O, P = 'gpurun_out/' + tag, 'profiles'
-for n in ('serl50', 'serl10', 'pop64', 'pop128', 'pop341', 'pop512', 'mixed', 'rccl1'):
+for n in ('serl50', 'total512', 'serl10', 'serl10_pop128', 'pop64', 'pop128', 'pop341', 'mixed', 'rccl1'):
     line = [l for l in open('%s/bench_%s.json' % (O, n)) if l.startswith('{')][-1]
     open('%s/%s_bench_%s.json' % (P, series, n), 'w').write(line)
-for n in ('serl50', 'serl10', 'pop341', 'pop512'):
+for n in ('serl50', 'serl10_pop128', 'pop512'):
     shutil.copy('%s/kernel_stats_%s.md' % (O, n), '%s/%s_kernel_stats_%s.md' % (P, series, n))
 shutil.copy(O + '/valu_latency.json', '%s/%s_valu_latency.json' % (P, series))
 shutil.copy(O + '/critical_path.json', '%s/%s_critical_path.json' % (P, series))
-open('%s/%s_cycle_profile.txt' % (P, series), 'w').write(open(O + '/ab.txt').read())
+open('%s/%s_cycle_profile.txt' % (P, series), 'w').write(''.join(open(O + '/' + f).read() for f in ('ab.txt', 'ab_prof1.txt', 'ab_prof2.txt') if __import__('os').path.exists(O + '/' + f)))
+shutil.copy(O + '/refill.json', '%s/%s_refill.json' % (P, series))
+shutil.copy(O + '/critical_path.json', P + '/floors_current.json')
 sq, pf, pw = (json.load(open('%s/pmc_%s.json' % (O, k))) for k in ('sq', 'fetch', 'write'))
 cp = json.load(open(O + '/critical_path.json'))
 b = json.loads(open('%s/%s_bench_serl50.json' % (P, series)).read())
@@ -35,9 +37,9 @@ pmc['issue'] = dict(
     simd_issue_frac=2 * sq['SQ_ACTIVE_INST_ANY'] / wc,
     valu_per_env_step=sq['SQ_INSTS_VALU'] / steps, salu_per_env_step=sq['SQ_INSTS_SALU'] / steps, lds_per_env_step=sq['SQ_INSTS_LDS'] / steps,
     issue_floor_us_per_env_step=cp['issue_floor_us_per_env_step'], dependency_floor_us_per_env_step=cp['dependency_floor_us_per_env_step'],
-    measured_us_per_env_step=b['t_step_us'], frac=cp['dependency_floor_us_per_env_step'] / b['t_step_us'],
-    frac_note='dependency floor (longest dependent chain of the model DAG at measured dependent-issue latencies, tools/dag/critical_path.py + '
-              'tools/valu_latency.hip) / measured time per env step',
+    measured_us_per_env_step=b['t_step_us'], issue_floor_frac=cp['issue_floor_us_per_env_step'] / b['t_step_us'],
+    frac_note='issue floor (minimal instruction count of the model DAG x 4 cycles over 4 SIMDs, tools/dag/critical_path.py) / measured time '
+              'per env step; the dependency floor weights a look-up with its own dependent chain (three LDS round trips, two divisions)',
     source='profiles/%s_pmc.json, profiles/%s_critical_path.json, profiles/%s_valu_latency.json' % (series, series, series))
 json.dump(pmc, open('%s/%s_pmc.json' % (P, series), 'w'), indent=1)
 json.dump(pmc, open(P + '/pmc_current.json', 'w'), indent=1)
