@@ -96,7 +96,7 @@ struct CitwLds {
   double inv[CITW_MAX_WAVES][CITW_INV_SLOTS];   // per-step invariants of the model (citw_<v>_step_invariants)
   double x[256];                          // team kernels: values that cross between the wavefronts at barrier B1
   double t3[48];
-  unsigned pflag[16]; double y[32 * CITW_GROUPS];
+  unsigned pflag[16]; double y[32 * CITW_GROUPS]; unsigned smiss;
   unsigned flag[16], iflag[16];           // hand-over flags of the team kernels (citw_flag_*, citw_iflag_*)
   alignas(16) float extra[CITW_LDS_EXTRA_FLOATS];     // unit-specific words (team kernels: actor hand-over + LDS-resident actor weights)
   double k[CITW_MAX_CONSTS];              // f64 literals of the model (only when generated with --lds-consts)
@@ -123,6 +123,7 @@ __shared__ CitwLds citw_lds;
 #define g_flag citw_lds.flag
 #define g_iflag citw_lds.iflag
 #define g_pflag citw_lds.pflag
+#define g_smiss citw_lds.smiss
 #define g_y citw_lds.y
 #define g_k citw_lds.k
 #define g_S citw_lds.S
@@ -160,6 +161,7 @@ __shared__ CitwLookup g_L[CITW_MAX_ROUNDS][2][64];
 
 __shared__ alignas(64) unsigned g_flag[16];      // hand-over flags of the team kernels, one per producing wavefront (citw_flag_*)
 __shared__ alignas(64) unsigned g_iflag[16];     // ... and for look-up inputs computed by helper wavefronts (citw_iflag_*)
+__shared__ alignas(64) unsigned g_smiss;         // sequence number of the last evaluation whose first search round had to repair an interval (citw_round_spec)
 __shared__ alignas(64) unsigned g_pflag[16];     // ... and for the values of the task graph behind the look-ups (citw_pflag_*)
 __shared__ alignas(64) double g_y[32 * CITW_GROUPS];   // team kernels: values that cross between the wavefronts BEHIND barrier B1 (task graph)
 #endif
@@ -292,6 +294,10 @@ static __device__ __forceinline__ void citw_search_part(const int wv, const Citw
   for (int base = PART * CITW_GROUP_LANES; base < COUNT; base += NPARTS * CITW_GROUP_LANES) citw_search_pass<MAXN, COUNT, SBASE>(wv, S, lane + base);
 }
 
+#ifndef CITW_SPEC_LOOKUP
+#define CITW_SPEC_LOOKUP 0       // 1: the interpolation passes run on the stored interval indices while the search lanes verify them (citw_round_spec).
+                                 // Measured SLOWER (r03 sweep 10: 20.9 against 20.15 us per env step), like the fused passes: off
+#endif
 #ifndef CITW_FUSED_LATER
 #define CITW_FUSED_LATER 0       // 1: ... in the look-up rounds behind the first one only (two 2-D + two 1-D tables on the chain every wavefront waits for)
 #endif
@@ -532,6 +538,73 @@ static __device__ __forceinline__ double citw_div_const(const double x, const do
   const double r = __builtin_fma(-q, c, x);
   const double q2 = __builtin_fma(r, rc, q);
   return __builtin_amdgcn_div_fixup(q2, c, x);
+}
+
+// ---- one look-up round of a single-episode wavefront with SPECULATION on the hints (round 3).  The index search is a
+// verification almost always (the intervals of 4 of 2 400 evaluations change), but as a pass of its own it stands in front of the
+// interpolation passes with three dependent LDS round trips, and its fall-back branch ends the basic block, so the compiler cannot
+// overlap it with them.  Here the interpolation passes read the interval indices the PREVIOUS evaluation left in g_sidx while the
+// search lanes re-verify them -- one straight-line block: the loads of all passes go out together, their arithmetic interleaves --
+// and ONE branch at the end handles a miss: full count (which repairs the slots), then the passes again.  The interval is
+// unique, so both paths produce the same bits.  Returns whether the wavefront took the miss path (wave-uniform).
+template <int SMAXN, int SCOUNT, int SBASE, int N2, int N1, typename OUT>
+static __device__ __forceinline__ bool citw_round_spec(const int wv, const CitwSearch *S, const CitwLookup *L2, const CitwLookup *L1,
+                                                       OUT &out, const int lane)
+{
+  static_assert(CITW_GROUP_LANES == 64 && SCOUNT <= 64 && N2 <= 64 && N1 <= 64, "one pass each");
+  // ---- verification of the hints (the hit path of citw_search_pass)
+  const bool sv = lane < SCOUNT;
+  const int sl = sv ? lane : 0;
+  const CitwSearch sd = S[sl];
+  const int stored = g_sidx[wv][SBASE + sl];
+  const double su = g_in[wv][sd.in];
+  const double *sx = g_bp[sd.row];
+  const int sn = sd.n;
+  int h = stored < 0 ? 0 : stored;
+  h = h > sn - 2 ? sn - 2 : h;
+  const bool ok = citw_hint_ok(h, sn, sx[h], sx[h + 1], su) && h == stored;
+  // ---- the interpolation passes on the stored indices
+  double r2 = 0.0, r1 = 0.0;
+  int o2 = 0, o1 = 0;
+  if constexpr (N2 > 0) {
+    const CitwLookup d = L2[lane < N2 ? lane : 0];
+    const int ix = g_sidx[wv][d.sx], iy = g_sidx[wv][d.sy];
+    const double u0 = g_in[wv][d.in0], u1 = g_in[wv][d.in1];
+    const double *xr = g_ro + d.xrw, *xc = g_ro + d.xcw, *z = g_ro + d.zw;
+    const int nr = d.nr;
+    const double x0 = xr[ix], x1 = xr[ix + 1];
+    const double dx = x1 - x0, wx = u0 - x0;
+    const double z00 = z[ix + nr * iy], z10 = z[ix + 1 + nr * iy];
+    const double z01 = z[ix + nr * (iy + 1)], z11 = z[ix + 1 + nr * (iy + 1)];
+    double a = z10 - z00; a = a / dx; a = a * wx; a = a + z00;
+    double b = z11 - z01; b = b / dx; b = b * wx; b = b + z01;
+    const double y0 = xc[iy];
+    const double dy = xc[iy + 1] - y0;
+    double r = b - a; r = r / dy; r = r * (u1 - y0);
+    r2 = r + a; o2 = d.out;
+  }
+  if constexpr (N1 > 0) {
+    const CitwLookup d = L1[lane < N1 ? lane : 0];
+    const int i = g_sidx[wv][d.sx];
+    const double u = g_in[wv][d.in0];
+    const double *x = g_ro + d.xrw, *y = g_ro + d.zw;
+    const double x0 = x[i], x1 = x[i + 1], y0 = y[i], y1 = y[i + 1];
+    double r = y1 - y0;
+    r = r / (x1 - x0);
+    r = r * (u - x0);
+    r1 = r + y0; o1 = d.out;
+  }
+  const bool miss = __ballot(sv && !ok) != 0ULL;
+  if (__builtin_expect(!miss, 1)) {
+    if constexpr (N2 > 0) { if (lane < N2) out[wv][o2] = r2; }
+    if constexpr (N1 > 0) { if (lane < N1) out[wv][o1] = r1; }
+  } else {
+    const int idx = citw_search_count<SMAXN>(sx, sn, su);
+    if (sv) g_sidx[wv][SBASE + sl] = idx;
+    if constexpr (N2 > 0) citw_lookup2d<N2>(wv, L2, out, lane);
+    if constexpr (N1 > 0) citw_lookup1d<N1>(wv, L1, out, lane);
+  }
+  return miss;
 }
 
 // ---- table3 S-function: 3-D table, linear interpolation.  The reference walks linearly from an interval cached in

@@ -663,19 +663,23 @@ class TeamGen(codegen.Gen):
                             waited.add(self.P)
                         B('  %s;' % TM(9))
                 sa = (R['maxn'], len(R['searches']), R['sbase'])
-                B('#if CITW_GROUP_LANES == 64 && %s   /* one episode per team: the look-up lanes verify the hints of their own index searches, no search pass */'
-                  % ('CITW_FUSED_LOOKUP' if r == 0 else '(CITW_FUSED_LOOKUP || CITW_FUSED_LATER)'))
-                if r == 0 and self.h1d is not None:
-                    B('  citw_iflag_raise(0, %s);   /* the look-up inputs are in g_in[0]: wave %d runs the 1-D pass beside the 2-D pass */' % (SEQ, self.h1d))
+                off1d = (r == 0 and self.h1d is not None)
+                B('#if CITW_GROUP_LANES == 64 && CITW_SPEC_LOOKUP   /* one episode per team: the interpolation passes run on the stored interval indices while the search lanes verify them */')
+                if off1d:
+                    B('  citw_iflag_raise(7, %s);   /* the look-up inputs are in g_in[0]: wave %d starts the 1-D pass on the stored indices */' % (SEQ, self.h1d))
                 if r == 0:
                     B('  %s;' % TM(6))
-                if R['L2']:
-                    B('  citw_lookup2d_fused<%d, %d, %d, %d>(%s, S[%d], L[%d][0], g_out%d, lane);' % ((len(R['L2']),) + sa + (row, R['tidx'], R['tidx'], R['oarr'])))
+                B('  {')
+                B('    const bool miss_ = citw_round_spec<%d, %d, %d, %d, %d>(%s, S[%d], L[%d][0], L[%d][1], g_out%d, lane);'
+                  % (sa + (len(R['L2']), 0 if off1d else len(R['L1']), row, R['tidx'], R['tidx'], R['tidx'], R['oarr'])))
+                if off1d:
+                    B('    if (miss_ && lane == 0) g_smiss = %s;   /* an interval had to be repaired: wave %d repeats its pass */' % (SEQ, self.h1d))
+                    B('    citw_iflag_raise(0, %s);   /* the interval indices in g_sidx[0] are verified */' % SEQ)
+                else:
+                    B('    (void)miss_;')
+                B('  }')
                 if r == 0:
                     B('  %s;' % TM(7))
-                if R['L1'] and not (r == 0 and self.h1d is not None):
-                    B('  citw_lookup1d_fused<%d, %d, %d, %d>(%s, S[%d], L[%d][1], g_out%d, lane);' % ((len(R['L1']),) + sa + (row, R['tidx'], R['tidx'], R['oarr'])))
-                if r == 0:
                     B('  %s;' % TM(8))
                 B('#else')
                 if r == 0 and self.l2_helpers and SHARE_SEARCH:
@@ -852,9 +856,12 @@ class TeamGen(codegen.Gen):
             if b != 0 and b == self.h1d:
                 B('  /* ---- the 1-D interpolation pass of round 1, taken over from wave 0 */')
                 R0_ = self.rounds[0]
-                B('#if CITW_GROUP_LANES == 64 && CITW_FUSED_LOOKUP')
-                B('  citw_iflag_wait(0, %s);   /* the look-up inputs are in g_in[0] */' % SEQ)
-                B('  citw_lookup1d_fused<%d, %d, %d, %d>(0, S[%d], L[%d][1], g_out0, lane);' % (len(R0_['L1']), R0_['maxn'], len(R0_['searches']), R0_['sbase'], R0_['tidx'], R0_['tidx']))
+                B('#if CITW_GROUP_LANES == 64 && CITW_SPEC_LOOKUP')
+                B('  citw_iflag_wait(7, %s);   /* the look-up inputs are in g_in[0] */' % SEQ)
+                B('  citw_lookup1d<%d>(0, L[%d][1], g_out0, lane);   /* on the interval indices of the previous evaluation ... */' % (len(R0_['L1']), R0_['tidx']))
+                B('  citw_iflag_wait(0, %s);   /* ... which wave 0 has verified by now */' % SEQ)
+                B('  if ((unsigned)__builtin_amdgcn_readfirstlane((int)g_smiss) == (unsigned)__builtin_amdgcn_readfirstlane((int)(%s)))' % SEQ)
+                B('    citw_lookup1d<%d>(0, L[%d][1], g_out0, lane);   /* (rare) an interval changed: once more on the repaired indices */' % (len(R0_['L1']), R0_['tidx']))
                 B('#else')
                 wait_searches(b)
                 if self.l2_helpers and SHARE_1D:
