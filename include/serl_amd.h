@@ -129,9 +129,11 @@ typedef struct serl_rollout_desc {
   int32_t max_steps;                /* rows in ref / trace buffers; 8001 for t_max = 80 */
   int32_t lanes_per_wave;           /* 0 = auto: wave-cooperative kernels chosen from the episode count -- a team of eight
                                        wavefronts per episode while every episode can have a CU of its own (episodes <=
-                                       CUs), two / four episodes per team up to 4 x CUs (hidden 32), rounds of those or one
-                                       wavefront per episode beyond; 1..64 = lane-per-episode kernels with that many
-                                       episodes per wavefront (nominal / ice code variants, attitude task only) */
+                                       CUs), two / four episodes per team up to 4 x CUs (hidden 32; other hidden sizes: two
+                                       per team up to 2 x CUs, six team + two actor wavefronts), beyond that ONE launch of
+                                       four-episode teams with a work queue (a lane group takes the next episode when its
+                                       own ends) or one wavefront per episode; 1..64 = lane-per-episode kernels with that
+                                       many episodes per wavefront (nominal / ice code variants, attitude task only) */
   int32_t concurrent_episodes;      /* episodes of OTHER serl_rollout calls expected to run at the same time on other
                                        streams (mixed-build sweeps: one call per dynamics build); the kernel and the
                                        wavefronts per workgroup are chosen for n_episodes + concurrent_episodes so that
