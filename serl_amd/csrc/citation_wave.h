@@ -20,6 +20,32 @@
 #include <stdint.h>
 
 #define CITW_MAX_ROUNDS 3
+
+// Timing experiments (never in a shipped build): CITW_ABLATE_MASK -- team wavefronts that skip their part of the evaluation
+// (rollout_team.inc); CITW_ABLATE_LOOK -- look-up passes that return at once (1: index searches, 2: 2-D, 4: 1-D, 8: the
+// precomputed lanes); CITW_NO_BARRIER -- the evaluation's two workgroup barriers left out.  Any of them freezes the state.
+#ifndef CITW_ABLATE_MASK
+#define CITW_ABLATE_MASK 0
+#endif
+#ifndef CITW_ABLATE_LOOK
+#define CITW_ABLATE_LOOK 0
+#endif
+#ifndef CITW_NO_BARRIER
+#define CITW_NO_BARRIER 0
+#endif
+#define CITW_ABLATE (CITW_ABLATE_MASK || CITW_ABLATE_LOOK || CITW_NO_BARRIER)
+#if CITW_ABLATE_LOOK & 32       // ... 32: pow, 64: sincos replaced by one multiplication; 128: no ODE5 combination
+#define pow(a, b) ((a) * (b))
+#endif
+#if CITW_ABLATE_LOOK & 64
+#define sincos(a, s, c) (*(s) = (a) * 0.5, *(c) = 1.0 - (a))
+#endif
+#if CITW_NO_BARRIER
+#define CITW_TEAM_BARRIER() ((void)0)
+#else
+#define CITW_TEAM_BARRIER() __syncthreads()
+#endif
+
 // Lanes that work for ONE episode.  64: the wavefront is the episode (rollout_wave.inc, rollout_team.inc).  32: two
 // episodes per wavefront, lanes 0-31 / 32-63 (rollout_half.inc) -- the scalar "glue" of the model costs an instruction
 // whether its 64 lanes hold one value or two, so packing two episodes into a wavefront nearly doubles the throughput in
@@ -29,6 +55,15 @@
 #ifndef CITW_GROUP_LANES
 #define CITW_GROUP_LANES 64
 #endif
+
+// Stores of wave-uniform values (look-up inputs, exchanged values, derivatives, hand-over flags) in the generated team code:
+// by lane 0 behind an exec-mask branch (0), or by every lane to the one address without a branch (1: the values, 2: the
+// flags, 3: both).  ~100 branches per evaluation less: one episode per team 20.3 -> 19.8 us per env step (r03 sweeps 19 - 21),
+// two per team 21.5 -> 21.0, four per team 24.8 -> 24.4 (lanes of a group store to the group's address).
+#ifndef CITW_UNIFORM_STORE
+#define CITW_UNIFORM_STORE 3
+#endif
+#define CITW_LANE0 ((CITW_UNIFORM_STORE & 1) != 0 || lane == 0)
 #define CITW_LANE ((int)(threadIdx.x & (CITW_GROUP_LANES - 1)))
 // Rows of the generated TEAM code (gen/citation_<variant>_team.inc): one episode per workgroup -> row 0 of every shared
 // blackboard, wave q's libm results in g_m[q], exchanged values from g_x[0]; with two episodes per team (lane groups,
@@ -219,13 +254,14 @@ __shared__ unsigned long long g_tlastw[16];    // ... and for the other waves (b
 static __device__ __forceinline__ void citw_flag_raise(int q, unsigned seq)
 {
   seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);     // (two episodes per team: the first one's model clock counts for both)
-  if ((threadIdx.x & 63) == 0) __hip_atomic_store(&g_flag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if ((CITW_UNIFORM_STORE & 2) || (threadIdx.x & 63) == 0) __hip_atomic_store(&g_flag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 static __device__ __forceinline__ void citw_flag_wait(int q, unsigned seq)
 {
   seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);     // (two episodes per team: the first one's model clock counts for both)
   // "reached", not "equal": a producer can never be an evaluation ahead (barrier B2 separates evaluations), but a poll that
   // tolerates it cannot hang either
+  if (CITW_ABLATE_LOOK & 256) return;      // (timing experiment: values "ready at once")
   while ((int)(__hip_atomic_load(&g_flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) CITW_POLL_PAUSE();
 }
 
@@ -233,7 +269,7 @@ static __device__ __forceinline__ void citw_flag_wait(int q, unsigned seq)
 static __device__ __forceinline__ void citw_iflag_raise(int q, unsigned seq)
 {
   seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);     // (two episodes per team: the first one's model clock counts for both)
-  if ((threadIdx.x & 63) == 0) __hip_atomic_store(&g_iflag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if ((CITW_UNIFORM_STORE & 2) || (threadIdx.x & 63) == 0) __hip_atomic_store(&g_iflag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 static __device__ __forceinline__ void citw_iflag_wait(int q, unsigned seq)
 {
@@ -246,12 +282,47 @@ static __device__ __forceinline__ void citw_iflag_wait(int q, unsigned seq)
 static __device__ __forceinline__ void citw_pflag_raise(int q, unsigned seq)
 {
   seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);
-  if ((threadIdx.x & 63) == 0) __hip_atomic_store(&g_pflag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if ((CITW_UNIFORM_STORE & 2) || (threadIdx.x & 63) == 0) __hip_atomic_store(&g_pflag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 static __device__ __forceinline__ void citw_pflag_wait(int q, unsigned seq)
 {
   seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);
+  if (CITW_ABLATE_LOOK & 512) return;
   while ((int)(__hip_atomic_load(&g_pflag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) CITW_POLL_PAUSE();
+}
+
+// Flag and value in ONE poll: the value's load is issued right behind the flag's (the LDS operations of a wavefront complete in
+// order, so a value loaded behind a raised flag is the published one) -- one LDS round trip on a hit instead of two
+#ifndef CITW_POLL_LOAD
+#define CITW_POLL_LOAD 1
+#endif
+static __device__ __forceinline__ double citw_poll_load_(const unsigned *flag, unsigned seq, const double *p)
+{
+#if CITW_POLL_LOAD
+  unsigned f;
+  double v;
+  do {
+    f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } while ((int)(f - seq) < 0);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return v;
+#else
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) CITW_POLL_PAUSE();
+  return *p;
+#endif
+}
+static __device__ __forceinline__ double citw_pflag_wait_load(int q, unsigned seq, const double *p)
+{
+  seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);
+  if (CITW_ABLATE_LOOK & 512) return *p;
+  return citw_poll_load_(&g_pflag[q], seq, p);
+}
+static __device__ __forceinline__ double citw_flag_wait_load(int q, unsigned seq, const double *p)
+{
+  seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);
+  if (CITW_ABLATE_LOOK & 256) return *p;
+  return citw_poll_load_(&g_flag[q], seq, p);
 }
 
 static __device__ __forceinline__ unsigned long long citw_d2u(double d) { return (unsigned long long)__double_as_longlong(d); }
@@ -295,8 +366,7 @@ static __device__ __forceinline__ void citw_search_part(const int wv, const Citw
 }
 
 #ifndef CITW_SPEC_LOOKUP
-#define CITW_SPEC_LOOKUP 0       // 1: the interpolation passes run on the stored interval indices while the search lanes verify them (citw_round_spec).
-                                 // Measured SLOWER (r03 sweep 10: 20.9 against 20.15 us per env step), like the fused passes: off
+#define CITW_SPEC_LOOKUP 1       // 1: single-episode team kernels precompute the hint-dependent half of wave 0's look-up lanes (citw_spec_pre / citw_spec_tail below)
 #endif
 #ifndef CITW_FUSED_LATER
 #define CITW_FUSED_LATER 0       // 1: ... in the look-up rounds behind the first one only (two 2-D + two 1-D tables on the chain every wavefront waits for)
@@ -354,6 +424,7 @@ static __device__ __forceinline__ int citw_search_count(const double *x, const i
 template <int MAXN, int COUNT, int SBASE>
 static __device__ __forceinline__ void citw_search_pass(const int wv, const CitwSearch *S, int ln)
 {
+  if (CITW_ABLATE_LOOK & 1) return;
   const bool valid = ln < COUNT;                      // (lanes beyond the round's searches hold a filler descriptor: they never store)
   const int lc = valid ? ln : 0;
   const CitwSearch d = S[lc];
@@ -384,6 +455,16 @@ static __device__ __forceinline__ void citw_search_pass(const int wv, const Citw
 #endif
 }
 
+// Searches FIRST .. FIRST + N - 1 of a round on the first N lanes of the lane group: the tables keyed on a look-up input that a
+// helper wavefront computes (gen/citation_<v>_team.inc: the air-data chain) are searched and interpolated by that helper, in
+// slots no other wavefront touches
+template <int MAXN, int FIRST, int N, int SBASE>
+static __device__ __forceinline__ void citw_search_range(const int wv, const CitwSearch *S, int lane)
+{
+  static_assert(N <= CITW_GROUP_LANES, "one pass");
+  citw_search_pass<MAXN, FIRST + N, SBASE>(wv, S, lane < N ? lane + FIRST : FIRST + N);
+}
+
 template <typename OUT>
 static __device__ __forceinline__ void citw_lookup2d_pass(const int wv, const CitwLookup *L, OUT &out, int lane);
 template <int COUNT = 64, typename OUT>
@@ -408,6 +489,7 @@ static __device__ __forceinline__ void citw_lookup2d_part(const int wv, const Ci
 template <typename OUT>
 static __device__ __forceinline__ void citw_lookup2d_pass(const int wv, const CitwLookup *L, OUT &out, int lane)
 {
+  if (CITW_ABLATE_LOOK & 2) return;
   const CitwLookup d = L[lane];
   const int ix = g_sidx[wv][d.sx], iy = g_sidx[wv][d.sy];
   const double u0 = g_in[wv][d.in0], u1 = g_in[wv][d.in1];
@@ -504,6 +586,15 @@ static __device__ __forceinline__ void citw_lookup1d(const int wv, const CitwLoo
   for (int base = 0; base < COUNT; base += CITW_GROUP_LANES) citw_lookup1d_pass(wv, L, out, lane + base);
 }
 
+// 1-D tables FIRST .. FIRST + N - 1 of a round on the first N lanes of the lane group (citw_search_range; the other lanes run
+// the filler descriptor 63)
+template <int FIRST, int N, typename OUT>
+static __device__ __forceinline__ void citw_lookup1d_range(const int wv, const CitwLookup *L, OUT &out, int lane)
+{
+  static_assert(N <= CITW_GROUP_LANES && FIRST + N <= 63, "one pass, and a filler row");
+  citw_lookup1d_pass(wv, L, out, lane < N ? lane + FIRST : 63);
+}
+
 // ... and of a 1-D round (two wavefronts at most)
 #define CITW_L1_SHARE(count) (((count) + CITW_GROUP_LANES - 1) / CITW_GROUP_LANES < 2 ? 1 : 2)
 template <int COUNT, int PART, int NPARTS, typename OUT>
@@ -516,6 +607,7 @@ static __device__ __forceinline__ void citw_lookup1d_part(const int wv, const Ci
 template <typename OUT>
 static __device__ __forceinline__ void citw_lookup1d_pass(const int wv, const CitwLookup *L, OUT &out, int lane)
 {
+  if (CITW_ABLATE_LOOK & 4) return;
   const CitwLookup d = L[lane];
   const int i = g_sidx[wv][d.sx];
   const double u = g_in[wv][d.in0];
@@ -540,70 +632,74 @@ static __device__ __forceinline__ double citw_div_const(const double x, const do
   return __builtin_amdgcn_div_fixup(q2, c, x);
 }
 
-// ---- one look-up round of a single-episode wavefront with SPECULATION on the hints (round 3).  The index search is a
-// verification almost always (the intervals of 4 of 2 400 evaluations change), but as a pass of its own it stands in front of the
-// interpolation passes with three dependent LDS round trips, and its fall-back branch ends the basic block, so the compiler cannot
-// overlap it with them.  Here the interpolation passes read the interval indices the PREVIOUS evaluation left in g_sidx while the
-// search lanes re-verify them -- one straight-line block: the loads of all passes go out together, their arithmetic interleaves --
-// and ONE branch at the end handles a miss: full count (which repairs the slots), then the passes again.  The interval is
-// unique, so both paths produce the same bits.  Returns whether the wavefront took the miss path (wave-uniform).
-template <int SMAXN, int SCOUNT, int SBASE, int N2, int N1, typename OUT>
-static __device__ __forceinline__ bool citw_round_spec(const int wv, const CitwSearch *S, const CitwLookup *L2, const CitwLookup *L1,
-                                                       OUT &out, const int lane)
+// ---- look-up lanes with the hint-dependent half PRECOMPUTED (single-episode team kernels, wave 0).  Of a 2-D interpolation
+//     a = (z10 - z00) / dx * (u0 - x0) + z00,  b = (z11 - z01) / dx * (u0 - x0) + z01,  r = (b - a) / dy * (u1 - y0) + a
+// only the underlined products depend on the inputs: the descriptor, the interval indices (the hints the previous evaluation
+// left in g_sidx), the four corners, the interval ends and BOTH x-direction quotients depend on the interval alone -- five
+// dependent LDS round trips and two of the three divisions.  citw_spec_pre() computes them at the top of the evaluation, where
+// they overlap the arithmetic of wave 0's input cones (one basic block); once the inputs are in g_in, citw_spec_tail() verifies
+// the hints on the search lanes (two compares against the preloaded interval ends) and finishes the interpolations: one LDS
+// round trip, one division.  Same operations on the same operands in the same order as citw_lookup2d_pass / citw_lookup1d_pass
+// (a 1-D table is the `a` half of a 2-D lane), so the bits are the same; if any search lane fails its test the caller runs the
+// plain passes, which repair the indices.  The lanes of ALL rounds are precomputed at once (merged descriptor row, one table per
+// lane): the later rounds' tails run behind barrier B1 on the registers of their lanes.
+struct CitwSpec {
+  double sxl, sxh;                           // search lane: ends of the stored interval
+  int sq;                                    // ... n | in << 8 | h << 16 | (h == stored) << 24
+  double x0, sa, z00, sb, z01, y0, dy;       // table lane
+  int tq;                                    // ... in0 | in1 << 8 | out << 16 | is1d << 24
+};
+
+template <int NS, int NT>
+static __device__ __forceinline__ CitwSpec citw_spec_pre(const int wv, const CitwSearch *S, const CitwLookup *L, const int lane)
 {
-  static_assert(CITW_GROUP_LANES == 64 && SCOUNT <= 64 && N2 <= 64 && N1 <= 64, "one pass each");
-  // ---- verification of the hints (the hit path of citw_search_pass)
-  const bool sv = lane < SCOUNT;
-  const int sl = sv ? lane : 0;
-  const CitwSearch sd = S[sl];
-  const int stored = g_sidx[wv][SBASE + sl];
-  const double su = g_in[wv][sd.in];
-  const double *sx = g_bp[sd.row];
-  const int sn = sd.n;
-  int h = stored < 0 ? 0 : stored;
-  h = h > sn - 2 ? sn - 2 : h;
-  const bool ok = citw_hint_ok(h, sn, sx[h], sx[h + 1], su) && h == stored;
-  // ---- the interpolation passes on the stored indices
-  double r2 = 0.0, r1 = 0.0;
-  int o2 = 0, o1 = 0;
-  if constexpr (N2 > 0) {
-    const CitwLookup d = L2[lane < N2 ? lane : 0];
+  static_assert(CITW_GROUP_LANES == 64 && NS <= 64 && NT <= 64, "one lane per search / table");
+  CitwSpec p;
+  if (CITW_ABLATE_LOOK & 8) { p.sxl = p.sxh = p.x0 = p.sa = p.z00 = p.sb = p.z01 = p.y0 = p.dy = 0.0; p.sq = p.tq = 0; return p; }
+  {
+    const CitwSearch d = S[lane < NS ? lane : 0];
+    const int stored = g_sidx[wv][d.pad];
+    const double *x = g_bp[d.row];
+    const int n = d.n;
+    int h = stored < 0 ? 0 : stored;
+    h = h > n - 2 ? n - 2 : h;
+    p.sxl = x[h]; p.sxh = x[h + 1];
+    p.sq = n | (int)d.in << 8 | h << 16 | (h == stored ? 1 : 0) << 24;
+  }
+  {
+    const CitwLookup d = L[lane < NT ? lane : 0];
     const int ix = g_sidx[wv][d.sx], iy = g_sidx[wv][d.sy];
-    const double u0 = g_in[wv][d.in0], u1 = g_in[wv][d.in1];
     const double *xr = g_ro + d.xrw, *xc = g_ro + d.xcw, *z = g_ro + d.zw;
     const int nr = d.nr;
     const double x0 = xr[ix], x1 = xr[ix + 1];
-    const double dx = x1 - x0, wx = u0 - x0;
+    const double dx = x1 - x0;
     const double z00 = z[ix + nr * iy], z10 = z[ix + 1 + nr * iy];
     const double z01 = z[ix + nr * (iy + 1)], z11 = z[ix + 1 + nr * (iy + 1)];
-    double a = z10 - z00; a = a / dx; a = a * wx; a = a + z00;
-    double b = z11 - z01; b = b / dx; b = b * wx; b = b + z01;
+    double a = z10 - z00; a = a / dx;
+    double b = z11 - z01; b = b / dx;
     const double y0 = xc[iy];
-    const double dy = xc[iy + 1] - y0;
-    double r = b - a; r = r / dy; r = r * (u1 - y0);
-    r2 = r + a; o2 = d.out;
+    p.x0 = x0; p.sa = a; p.z00 = z00; p.sb = b; p.z01 = z01; p.y0 = y0; p.dy = xc[iy + 1] - y0;
+    p.tq = (int)d.in0 | (int)d.in1 << 8 | (int)d.out << 16 | (int)d.p1 << 24;
   }
-  if constexpr (N1 > 0) {
-    const CitwLookup d = L1[lane < N1 ? lane : 0];
-    const int i = g_sidx[wv][d.sx];
-    const double u = g_in[wv][d.in0];
-    const double *x = g_ro + d.xrw, *y = g_ro + d.zw;
-    const double x0 = x[i], x1 = x[i + 1], y0 = y[i], y1 = y[i + 1];
-    double r = y1 - y0;
-    r = r / (x1 - x0);
-    r = r * (u - x0);
-    r1 = r + y0; o1 = d.out;
-  }
-  const bool miss = __ballot(sv && !ok) != 0ULL;
-  if (__builtin_expect(!miss, 1)) {
-    if constexpr (N2 > 0) { if (lane < N2) out[wv][o2] = r2; }
-    if constexpr (N1 > 0) { if (lane < N1) out[wv][o1] = r1; }
-  } else {
-    const int idx = citw_search_count<SMAXN>(sx, sn, su);
-    if (sv) g_sidx[wv][SBASE + sl] = idx;
-    if constexpr (N2 > 0) citw_lookup2d<N2>(wv, L2, out, lane);
-    if constexpr (N1 > 0) citw_lookup1d<N1>(wv, L1, out, lane);
-  }
+  return p;
+}
+
+// search lanes [S0, S1) verify, table lanes [T0, T1) interpolate and -- if every search lane confirmed its interval -- store;
+// returns whether a lane missed (wave-uniform): then nothing was stored and the caller runs the plain passes of the round
+template <int S0, int S1, int T0, int T1, typename OUT>
+static __device__ __forceinline__ bool citw_spec_tail(const int wv, const CitwSpec &p, OUT &out, const int lane)
+{
+  if (CITW_ABLATE_LOOK & 8) return false;
+  const double su = g_in[wv][(p.sq >> 8) & 255];
+  const double u0 = g_in[wv][p.tq & 255], u1 = g_in[wv][(p.tq >> 8) & 255];
+  const bool ok = citw_hint_ok((p.sq >> 16) & 255, p.sq & 255, p.sxl, p.sxh, su) && (p.sq >> 24) != 0;
+  const double wx = u0 - p.x0;
+  double a = p.sa * wx; a = a + p.z00;
+  double b = p.sb * wx; b = b + p.z01;
+  double r = b - a; r = r / p.dy; r = r * (u1 - p.y0);
+  const double res = (p.tq >> 24) != 0 ? a : r + a;
+  const bool miss = __ballot(lane >= S0 && lane < S1 && !ok) != 0ULL;
+  if (!miss && lane >= T0 && lane < T1) out[wv][(p.tq >> 16) & 255] = res;
   return miss;
 }
 

@@ -452,24 +452,45 @@ class Gen:
         out = []
         P = out.append
         lw = self.low
-        P('static __device__ const CitwSearch %s_search[%d][64] = {' % (pre, len(self.all_rounds)))
+        srows = lambda R: ['{%d, %d, %d, %d}' % (self.bpvec.index((s[0], s[1])), s[1], R['ibase'] + s[2], R['sbase'] + k) for k, s in enumerate(R['searches'])]
+        rows2 = lambda R: ['{%d, %d, %d, %d, %d, %d, %d, %d, %d, %d}' % ((e['xr'] >> 3) - lw, e['nr'], (e['xc'] >> 3) - lw, (e['z'] >> 3) - lw, R['sbase'] + e['sx'], R['sbase'] + e['sy'],
+                                                                        R['ibase'] + e['in0'], R['ibase'] + e['in1'], R['obase2'] + k, e['nc']) for k, e in enumerate(R['L2'])]
+        rows1 = lambda R: ['{%d, %d, 0, %d, %d, 0, %d, 0, %d}' % ((e['x'] >> 3) - lw, e['n'], (e['y'] >> 3) - lw, R['sbase'] + e['sx'], R['ibase'] + e['in0'], 64 + R['obase1'] + k)
+                           for k, e in enumerate(R['L1'])]
+        # a 1-D table as the first half of a 2-D lane (citw_spec_pre / citw_spec_tail: nr = 0, both axes the same search, p1 = 1)
+        rows1as2 = lambda R: ['{%d, 0, %d, %d, %d, %d, %d, %d, %d, %d, 1}' % ((e['x'] >> 3) - lw, (e['x'] >> 3) - lw, (e['y'] >> 3) - lw, R['sbase'] + e['sx'], R['sbase'] + e['sx'],
+                                                                            R['ibase'] + e['in0'], R['ibase'] + e['in0'], 64 + R['obase1'] + k, e['n']) for k, e in enumerate(R['L1'])]
+        fill_s, fill_2, fill_1 = '{0, 2, 0, 0}', '{0, 2, 0, 0, 63, 63, 0, 0, 127, 2}', '{0, 2, 0, 0, 63, 0, 0, 0, 127}'
+        spec = getattr(self, 'spec', None)
+        P('static __device__ const CitwSearch %s_search[%d][64] = {' % (pre, len(self.all_rounds) + (1 if spec else 0)))
         for R in self.all_rounds:
-            rows = ['{%d, %d, %d, %d}' % (self.bpvec.index((s[0], s[1])), s[1], R['ibase'] + s[2], R['sbase'] + k) for k, s in enumerate(R['searches'])]
-            rows += ['{0, 2, 0, 0}'] * (64 - len(rows))
+            rows = srows(R)
+            rows += [fill_s] * (64 - len(rows))
             P('  {' + ', '.join(rows) + '},')
+        if spec:
+            # the merged row of citw_spec_pre: wave 0's searches of round 1, then the later rounds' (one lane each)
+            rows = srows(self.rounds[0])[:spec['ns'][0][1]]
+            for R in self.rounds[1:]:
+                rows += srows(R)
+            assert len(rows) == spec['NS']
+            P('  {' + ', '.join(rows + [fill_s] * (64 - len(rows))) + '},')
         P('};')
         P('enum { %s_NBP = %d };' % (pre, len(self.bpvec)))
         P('static __device__ const CitwBpVec %s_bpvec[%d] = {%s};' % (pre, len(self.bpvec), ', '.join('{%d, %d}' % ((a >> 3) - lw, n) for a, n in self.bpvec)))
-        P('static __device__ const CitwLookup %s_lookup[%d][2][64] = {' % (pre, len(self.all_rounds)))
+        P('static __device__ const CitwLookup %s_lookup[%d][2][64] = {' % (pre, len(self.all_rounds) + (1 if spec else 0)))
         for R in self.all_rounds:
-            rows2 = ['{%d, %d, %d, %d, %d, %d, %d, %d, %d, %d}' % ((e['xr'] >> 3) - lw, e['nr'], (e['xc'] >> 3) - lw, (e['z'] >> 3) - lw, R['sbase'] + e['sx'], R['sbase'] + e['sy'],
-                                                                   R['ibase'] + e['in0'], R['ibase'] + e['in1'], R['obase2'] + k, e['nc']) for k, e in enumerate(R['L2'])]
-            rows2 += ['{0, 2, 0, 0, 63, 63, 0, 0, 127, 2}'] * (64 - len(rows2))
-            rows1 = ['{%d, %d, 0, %d, %d, 0, %d, 0, %d}' % ((e['x'] >> 3) - lw, e['n'], (e['y'] >> 3) - lw, R['sbase'] + e['sx'], R['ibase'] + e['in0'], 64 + R['obase1'] + k)
-                     for k, e in enumerate(R['L1'])]
-            rows1 += ['{0, 2, 0, 0, 63, 0, 0, 0, 127}'] * (64 - len(rows1))
-            P('  {{' + ', '.join(rows2) + '},')
-            P('   {' + ', '.join(rows1) + '}},')
+            r2, r1 = rows2(R), rows1(R)
+            r2 += [fill_2] * (64 - len(r2))
+            r1 += [fill_1] * (64 - len(r1))
+            P('  {{' + ', '.join(r2) + '},')
+            P('   {' + ', '.join(r1) + '}},')
+        if spec:
+            rows = rows2(self.rounds[0])
+            for R in self.rounds[1:]:
+                rows += rows2(R) + rows1as2(R)
+            assert len(rows) == spec['NT']
+            P('  {{' + ', '.join(rows + [fill_2] * (64 - len(rows))) + '},')
+            P('   {' + ', '.join([fill_1] * 64) + '}},')
         P('};')
         return out
 

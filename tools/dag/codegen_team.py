@@ -67,6 +67,9 @@ SPREAD_MIN = float(os.environ.get('CITW_TEAM_SPREAD_MIN', 0))         # with SPR
 SIMD_PAIRS = int(os.environ.get('CITW_TEAM_SIMD_PAIRS', 0))            # 1: the balancer counts the load of a SIMD (waves b and b + 4 share one) instead of a wave's
 ACTOR_UNITS = float(os.environ.get('CITW_TEAM_ACTOR_UNITS', 550))     # the actor wavefront (wave index K) as load on the SIMD it shares, units per evaluation
 ACTOR_POST = float(os.environ.get('CITW_TEAM_ACTOR_POST', 0))
+SPEC = int(os.environ.get('CITW_TEAM_SPEC', 1))                        # 1: emit the merged descriptor row + the precomputed look-up lanes of wave 0 (citw_spec_pre / citw_spec_tail; compiled in with -DCITW_SPEC_LOOKUP=1)
+STAGE0 = int(os.environ.get('CITW_TEAM_STAGE0', 1))                    # 1: glue that depends on the command vector alone runs in the first of the six evaluations only (its look-up inputs / exchanged values keep their LDS slots)
+OWN_LOOKUPS = int(os.environ.get('CITW_TEAM_OWN_LOOKUPS', 0))          # 1: the helper that computes a look-up input also searches / interpolates the (1-D) tables keyed on it: wave 0 never waits for it
 SPLIT_IN = int(os.environ.get('CITW_TEAM_SPLIT_INPUTS', 1))           # 1: the heaviest round-1 input cone (pow chain) runs on a helper, handed over by flag
 FN_SCALE = float(os.environ.get('CITW_TEAM_FN_SCALE', 1.0))            # libm bodies relative to the first estimates in FN
 LIBM_SCALE = float(os.environ.get('CITW_TEAM_LIBM_SCALE', 1.0))        # extra factor for the handed-over cone's libm bodies
@@ -82,6 +85,15 @@ TASK_MIN = float(os.environ.get('CITW_TEAM_TASK_MIN', 12))         # ... into pi
 TASK_COMM = float(os.environ.get('CITW_TEAM_TASK_COMM', 24))       # cost units between "value stored" and "value usable on another wavefront" (LDS store, flag, poll, load)
 CW = dict(div=11, sqrt=15, sel=3, unord=2, table3=120)
 FN = dict(sc_sin=100, sc_cos=100, sin=100, cos=100, tan=120, exp=40, log10=60, log=60, atan=80, pow=250)
+
+
+def n_search(R):
+    """index searches of a round that wave 0's passes cover (the rest belongs to the helper that computes their input)"""
+    return R.get('ns_main', len(R['searches']))
+
+
+def n_l1(R):
+    return R.get('n1_main', len(R['L1']))
 
 
 class TeamGen(codegen.Gen):
@@ -149,6 +161,30 @@ class TeamGen(codegen.Gen):
                 self.P = K - 1
                 self.in_owner[heavy] = self.P
         self.spread = bool(SPREAD_IN and K > 2 and ins0 and SHARE_LIBM)
+        # ---- the tables keyed on P's input.  If they are all 1-D (nominal: two 3-point tables on the calibrated airspeed), P
+        # searches and interpolates them itself as soon as it has the input -- on its first lanes, with the same pass functions,
+        # in slots of their own at the END of the round's search / 1-D lists -- and wave 0 starts its passes without polling P.
+        self.own_lk = None
+        R0 = self.rounds[0]
+        if OWN_LOOKUPS and self.P is not None and not (SPREAD_IN and K > 2) and self.chain_round is None and 'ns_main' not in R0:
+            kh = [k for k, n in enumerate(R0['ins']) if self.in_owner[n] == self.P]
+            mv_l = [e for e in R0['L1'] if e['in0'] in kh]
+            if not any(e['in0'] in kh or e['in1'] in kh for e in R0['L2']) and 0 < len(mv_l) <= 16:
+                mv_s = [i for i, sr in enumerate(R0['searches']) if sr[2] in kh]
+                keep_s = [i for i in range(len(R0['searches'])) if i not in mv_s]
+                newpos = {old: new for new, old in enumerate(keep_s + mv_s)}
+                R0['searches'] = [R0['searches'][i] for i in keep_s + mv_s]
+                for e in R0['L2']:
+                    e['sx'], e['sy'] = newpos[e['sx']], newpos[e['sy']]
+                for e in R0['L1']:
+                    e['sx'] = newpos[e['sx']]
+                R0['L1'] = [e for e in R0['L1'] if e['in0'] not in kh] + mv_l
+                for k, e in enumerate(R0['L1']):
+                    self.outslot[e['node']] = (R0['oarr'], 64 + R0['obase1'] + k)
+                R0['ns_main'], R0['n1_main'] = len(keep_s), len(R0['L1']) - len(mv_l)
+                assert len(mv_s) <= 16
+        if 'ns_main' in R0:
+            self.own_lk = (R0['ns_main'], len(R0['searches']) - R0['ns_main'], R0['n1_main'], len(R0['L1']) - R0['n1_main'])
         if self.spread:
             # every input cone goes to a helper (heaviest first, to the least loaded one; the pow chain stays with P); wave 0
             # keeps the look-up phases only
@@ -308,6 +344,58 @@ class TeamGen(codegen.Gen):
                         self.exp[p].append(n)
                     self.imp[b].append(n)
         assert len(self.xslot) <= 256
+        # ---- per-step invariants.  Actuator saturations, the gear / flap logic ... depend on the command vector (and constants)
+        # alone: 54 of the 120 nodes wave 0 computes in front of its index search.  They are the same in all six evaluations of
+        # an env step, so a wavefront computes them in the first one only (`if (stage == 0)`, a scalar branch) -- provided every
+        # consumer ON THAT WAVEFRONT is part of the block: the results leave through LDS slots that nothing else writes (look-up
+        # inputs in g_in: the later rounds' inputs move behind round 1's; exchanged values in g_x), registers do not survive.
+        self.stage0 = [set() for _ in range(K)]
+        if STAGE0 and K > 1 and not self.inv_frontier:
+            const_states = [i for i, n in enumerate(self.xdot) if g.nodes[n] == ('cf', 0)]
+            sinv = {}
+            for n in self.order:
+                t = g.nodes[n]
+                if t[0] == 'in':
+                    sinv[n] = t[1] in ('CMD', 'RO') or (t[1] == 'X' and t[2] in const_states)
+                elif t[0] in ('cf', 'ci', 'true', 'false'):
+                    sinv[n] = True
+                elif t[0] in LOOKUPS or t[0] in FN or t[0] == 'in_i' or n in shared or n in self.libm_slot:
+                    sinv[n] = False
+                else:
+                    sinv[n] = all(sinv[c] for c in build_dag.children(g, n))
+            later = set()
+            for R in self.rounds[1:]:
+                for n in R['ins']:
+                    later |= set(self.closure_all(n))
+            for b in range(K):
+                mine = set(have[b]) | set(phave[b]) | (later if b == self.EW else set())
+                if b == 0:
+                    mine |= set(self.rounds[0]['ins'])
+                blk = set(n for n in have[b] if sinv[n] and g.nodes[n][0] not in LEAF)
+                changed = True
+                while changed:
+                    changed = False
+                    for n in list(blk):
+                        if any(u in mine and u not in blk for u in users[n]) or n in rootset or n == self.stop:
+                            blk.discard(n); changed = True
+                self.stage0[b] = blk
+            if any(n in self.stage0[0] for n in self.rounds[0]['ins']):
+                off = len(self.rounds[0]['ins'])
+                for R in self.rounds[1:]:
+                    R['ibase'] = off
+                    off += len(R['ins'])
+                assert off <= 32
+        # ---- precomputed look-up lanes (citation_wave.h: citw_spec_pre / citw_spec_tail): one lane per search and per table of
+        # ALL rounds in a merged descriptor row behind the rounds' own rows
+        self.spec = None
+        if SPEC and K > 1 and self.chain_round is None and len(self.all_rounds) < 3 and not (SPREAD_IN and K > 2):
+            R0 = self.rounds[0]
+            ns, nt = [(0, n_search(R0))], [(0, len(R0['L2']))]
+            for R in self.rounds[1:]:
+                ns.append((ns[-1][1], ns[-1][1] + len(R['searches'])))
+                nt.append((nt[-1][1], nt[-1][1] + len(R['L2']) + len(R['L1'])))
+            if ns[-1][1] <= 64 and nt[-1][1] <= 64:
+                self.spec = dict(ns=ns, nt=nt, NS=ns[-1][1], NT=nt[-1][1], tidx=len(self.all_rounds))
         # ---- owners of the outputs
         def out_owner(n):
             if n in post:
@@ -494,7 +582,7 @@ class TeamGen(codegen.Gen):
               % (self.EW, len(RC['ins']), len(RC['searches']), len(RC['L2']), len(RC['L1']), 'the chain round' if CHAIN_B1 == 'rc' else 'round 2'))
         # the team's own descriptor tables (the rounds differ from the one-wave kernels' when the engine chain is split off)
         P('#define CITW_TEAM_TABLES 1')
-        P('enum { citw_%s_team_ROUNDS = %d };' % (V, len(self.all_rounds)))
+        P('enum { citw_%s_team_ROUNDS = %d };' % (V, len(self.all_rounds) + (1 if self.spec else 0)))
         for line in self.table_lines('citw_%s_team' % V):
             P(line)
         if self.tasks is not None:
@@ -532,9 +620,10 @@ class TeamGen(codegen.Gen):
                         if m in shared:
                             q, sl = self.row_slot[m]
                             if q != b and q not in waited and not after_b1[0]:
-                                B('  citw_flag_wait(%d, %s);   /* libm results of wave %d */' % (q, SEQ, q))
+                                B('  const double v%d = citw_flag_wait_load(%d, %s, &g_m[%d][%d]);   /* libm results of wave %d */' % (m, q, SEQ, q, sl, q))
                                 waited.add(q)
-                            B('  const double v%d = g_m[%d][%d];' % (m, q, sl))
+                            else:
+                                B('  const double v%d = g_m[%d][%d];' % (m, q, sl))
                             continue
                         if t[0] in LOOKUPS:
                             assert self.outslot[m][0] in done_rounds, 'look-up result used before its round'
@@ -567,7 +656,7 @@ class TeamGen(codegen.Gen):
                 for j in calls:
                     if j in self.call_guard:
                         emit_node(self.call_guard[j][0])     # the condition under which this call's result is used at all
-                B('  if (lane == 0) {')
+                B('  if (CITW_LANE0) {')
                 for j in calls:
                     B('    g_m[%d][%d] = %s;' % (b, 48 + self.calls_of[b].index(j), self.ref(self.libm_calls[j][0][1])))
                 B('  }')
@@ -608,7 +697,7 @@ class TeamGen(codegen.Gen):
                 for (fn, arg, prm), outs in lst:
                     emit_node(arg)
                 self.libm_slot = slot
-                B('  if (lane == 0) {')
+                B('  if (CITW_LANE0) {')
                 for j, ((fn, arg, prm), outs) in enumerate(lst):
                     B('    g_m[wv][%d] = %s;' % (48 + j, self.ref(arg)))
                 B('  }')
@@ -645,11 +734,16 @@ class TeamGen(codegen.Gen):
                 B('  /* ---- look-up round %s */' % ('1' if r == 0 else ('chain (engine tables of round 1)' if r == 'c' else str(r + 1))))
                 row = 'wv' if b == 0 else '0'           # (text substitution below: wave 0's own row IS row 0 of the shared blackboards)
                 mine = [(k, n) for k, n in enumerate(R['ins']) if r != 0 or self.in_owner[n] == 0]
+                if r == 0 and b == 0 and self.spec is not None:
+                    B('#if CITW_GROUP_LANES == 64 && CITW_SPEC_LOOKUP   /* the hint-dependent half of every look-up lane (all rounds), in front of the input cones it overlaps */')
+                    B('  const CitwSpec sp_ = citw_spec_pre<%d, %d>(%s, S[%d], L[%d][0], lane);' % (self.spec['NS'], self.spec['NT'], row, self.spec['tidx'], self.spec['tidx']))
+                    B('#endif')
                 for k, n in mine:
                     emit_node(n, allowed)
-                B('  if (lane == 0) {')
+                B('  if (CITW_LANE0) {')
                 for k, n in mine:
-                    B('    g_in[%s][%d] = %s;' % (row, R['ibase'] + k, self.ref(n)))
+                    if not (r == 0 and n in self.stage0[b]):
+                        B('    g_in[%s][%d] = %s;' % (row, R['ibase'] + k, self.ref(n)))
                 B('  }')
                 if r == 0:
                     B('  %s;' % TM(5))
@@ -657,33 +751,37 @@ class TeamGen(codegen.Gen):
                         for q in sorted(set(self.in_owner.values()) - {0}):
                             B('  citw_iflag_wait(%d, %s);   /* the look-up inputs wave %d computes are in g_in[0] */' % (q, SEQ, q))
                         B('  %s;' % TM(9))
-                    elif self.P is not None:
+                    elif self.P is not None and self.own_lk is None:
                         if self.P not in waited:
                             B('  citw_flag_wait(%d, %s);   /* the input(s) wave %d computes are in g_in[0] */' % (self.P, SEQ, self.P))
                             waited.add(self.P)
                         B('  %s;' % TM(9))
-                sa = (R['maxn'], len(R['searches']), R['sbase'])
+                sa = (R['maxn'], n_search(R), R['sbase'])
                 off1d = (r == 0 and self.h1d is not None)
-                B('#if CITW_GROUP_LANES == 64 && CITW_SPEC_LOOKUP   /* one episode per team: the interpolation passes run on the stored interval indices while the search lanes verify them */')
-                if off1d:
-                    B('  citw_iflag_raise(7, %s);   /* the look-up inputs are in g_in[0]: wave %d starts the 1-D pass on the stored indices */' % (SEQ, self.h1d))
-                if r == 0:
-                    B('  %s;' % TM(6))
-                B('  {')
-                B('    const bool miss_ = citw_round_spec<%d, %d, %d, %d, %d>(%s, S[%d], L[%d][0], L[%d][1], g_out%d, lane);'
-                  % (sa + (len(R['L2']), 0 if off1d else len(R['L1']), row, R['tidx'], R['tidx'], R['tidx'], R['oarr'])))
-                if off1d:
-                    B('    if (miss_ && lane == 0) g_smiss = %s;   /* an interval had to be repaired: wave %d repeats its pass */' % (SEQ, self.h1d))
-                    B('    citw_iflag_raise(0, %s);   /* the interval indices in g_sidx[0] are verified */' % SEQ)
-                else:
-                    B('    (void)miss_;')
-                B('  }')
-                if r == 0:
-                    B('  %s;' % TM(7))
-                    B('  %s;' % TM(8))
-                B('#else')
+                sp = self.spec if (b == 0 and self.spec is not None) else None
+                if sp is not None:
+                    ri = 0 if r == 0 else r
+                    B('#if CITW_GROUP_LANES == 64 && CITW_SPEC_LOOKUP   /* one episode per team: the look-up lanes were precomputed on the stored intervals (citw_spec_pre above) */')
+                    if r == 0:
+                        B('  %s;' % TM(6))
+                    B('  if (citw_spec_tail<%d, %d, %d, %d>(%s, sp_, g_out%d, lane)) {   /* (rare) an interval moved: the plain passes, which repair the stored indices */'
+                      % (sp['ns'][ri] + sp['nt'][ri] + (row, R['oarr'])))
+                    B('    citw_search<%d, %d, %d>(%s, S[%d], lane);' % (sa + (row, R['tidx'])))
+                    if R['L2']:
+                        B('    citw_lookup2d<%d>(%s, L[%d][0], g_out%d, lane);' % (len(R['L2']), row, R['tidx'], R['oarr']))
+                    if R['L1'] and r != 0:
+                        B('    citw_lookup1d<%d>(%s, L[%d][1], g_out%d, lane);' % (len(R['L1']), row, R['tidx'], R['oarr']))
+                    B('  }')
+                    if off1d:
+                        B('  citw_iflag_raise(0, %s);   /* the interval indices in g_sidx[0] are verified: wave %d runs the 1-D pass */' % (SEQ, self.h1d))
+                    elif r == 0 and R['L1']:
+                        B('  citw_lookup1d<%d>(%s, L[%d][1], g_out%d, lane);' % (n_l1(R), row, R['tidx'], R['oarr']))
+                    if r == 0:
+                        B('  %s;' % TM(7))
+                        B('  %s;' % TM(8))
+                    B('#else')
                 if r == 0 and self.l2_helpers and SHARE_SEARCH:
-                    ns = len(R['searches'])
+                    ns = n_search(R)
                     B('#if CITW_SEARCH_SHARE(%d) > 1   /* several episodes per team: the search passes are shared with waves 2 (and 4) */' % ns)
                     B('  citw_iflag_raise(7, %s);   /* the look-up inputs are in g_in[0] */' % SEQ)
                     B('  citw_search_part<%d, %d, 0, CITW_SEARCH_SHARE(%d), %d>(wv, S[%d], lane);' % (R['maxn'], ns, ns, R['sbase'], R['tidx']))
@@ -693,7 +791,7 @@ class TeamGen(codegen.Gen):
                     B('  citw_iflag_wait(%d, %s);' % (SEARCH_WAVES[1], SEQ))
                     B('#endif')
                     B('#else')
-                B('  citw_search<%d, %d, %d>(%s, S[%d], lane);' % (R['maxn'], len(R['searches']), R['sbase'], row, R['tidx']))
+                B('  citw_search<%d, %d, %d>(%s, S[%d], lane);' % (R['maxn'], n_search(R), R['sbase'], row, R['tidx']))
                 if r == 0 and self.h1d is not None:
                     B('  citw_iflag_raise(0, %s);   /* interval indices are in g_sidx[0]: wave %d runs the 1-D pass beside the 2-D pass */' % (SEQ, self.h1d))
                 if r == 0 and self.l2_helpers and SHARE_SEARCH:
@@ -707,10 +805,11 @@ class TeamGen(codegen.Gen):
                 if r == 0:
                     B('  %s;' % TM(7))
                 if R['L1'] and not (r == 0 and self.h1d is not None):
-                    B('  citw_lookup1d<%d>(%s, L[%d][1], g_out%d, lane);' % (len(R['L1']), row, R['tidx'], R['oarr']))
+                    B('  citw_lookup1d<%d>(%s, L[%d][1], g_out%d, lane);' % (n_l1(R), row, R['tidx'], R['oarr']))
                 if r == 0:
                     B('  %s;' % TM(8))
-                B('#endif')
+                if sp is not None:
+                    B('#endif')
 
             B('static __device__ CITW_EVAL_INLINE double citw_%s_team_eval_w%d(const int stage, const double T, const unsigned TICK, const unsigned FSEQ)' % (V, b))
             B('{')
@@ -744,6 +843,25 @@ class TeamGen(codegen.Gen):
                 for n in self.inv_frontier:
                     B(self.inv_load(n))
                     emitted.add(n)
+            blk = self.stage0[b]
+            if blk:
+                for n in [m for m in self.order if m in blk]:
+                    for c in build_dag.children(g, n):
+                        if c not in blk and g.nodes[c][0] not in LEAF:
+                            emit_node(c, self.have[b])
+                B('  if (stage == 0) {   /* ---- what depends on the command vector alone: once per env step; its look-up inputs and exchanged values keep their LDS slots */')
+                for n in [m for m in self.order if m in blk]:
+                    emit_node(n, self.have[b])
+                B('  if (CITW_LANE0) {')
+                if b == 0:
+                    for k, n in enumerate(self.rounds[0]['ins']):
+                        if n in blk:
+                            B('    g_in[wv][%d] = %s;' % (self.rounds[0]['ibase'] + k, self.ref(n)))
+                for n in self.exp[b]:
+                    if n in blk:
+                        B('    g_x[%d] = %s;' % (self.xslot[n], ('%s ? 1.0 : 0.0' % self.ref(n)) if g.ty[n] == 'b' else self.ref(n)))
+                B('  }')
+                B('  }')
             if self.spread:
                 pass          # (inputs follow the libm phase below)
             elif b == self.P:
@@ -755,13 +873,19 @@ class TeamGen(codegen.Gen):
                 for k, n in enumerate(self.rounds[0]['ins']):
                     if self.in_owner[n] == b:
                         emit_node(n, self.have[b])
-                B('  if (lane == 0) {')
+                B('  if (CITW_LANE0) {')
                 for k, n in enumerate(self.rounds[0]['ins']):
                     if self.in_owner[n] == b:
                         B('    g_in[0][%d] = %s;' % (k, self.ref(n)))
                 B('  }')
                 B('  citw_flag_raise(%d, %s);' % (b, SEQ))
                 B('  __builtin_amdgcn_sched_barrier(0);     /* nothing of what follows may be scheduled in front of the hand-over */')
+                if self.own_lk is not None:
+                    R0_ = self.rounds[0]
+                    ns_, nso_, n1_, n1o_ = self.own_lk
+                    B('  /* ---- ... and the %d 1-D table(s) keyed on it: searched and interpolated here (slots of their own), wave 0 does not wait */' % n1o_)
+                    B('  citw_search_range<%d, %d, %d, %d>(CITW_TROW, S[%d], lane);' % (max(sr[1] for sr in R0_['searches'][ns_:]), ns_, nso_, R0_['sbase'], R0_['tidx']))
+                    B('  citw_lookup1d_range<%d, %d>(CITW_TROW, L[%d][1], g_out0, lane);' % (n1_, n1o_, R0_['tidx']))
             if shared:
                 libm_phase_shared()
             else:
@@ -771,7 +895,7 @@ class TeamGen(codegen.Gen):
                 for k, n in enumerate(self.rounds[0]['ins']):
                     if self.in_owner[n] == b:
                         emit_node(n, self.have[b])
-                B('  if (lane == 0) {')
+                B('  if (CITW_LANE0) {')
                 for k, n in enumerate(self.rounds[0]['ins']):
                     if self.in_owner[n] == b:
                         B('    g_in[0][%d] = %s;' % (k, self.ref(n)))
@@ -795,7 +919,7 @@ class TeamGen(codegen.Gen):
                     done_rounds.discard(0)
             def emit_search_share(bb):
                 kq = SEARCH_WAVES.index(bb) + 1
-                nsq = len(self.rounds[0]['searches'])
+                nsq = n_search(self.rounds[0])
                 B('#if CITW_SEARCH_SHARE(%d) > %d   /* several episodes per team: search pass %d, beside wave 0 */' % (nsq, kq, kq))
                 B('  citw_iflag_wait(7, %s);' % SEQ)
                 B('  citw_search_part<%d, %d, %d, CITW_SEARCH_SHARE(%d), %d>(0, S[0], lane);' % (self.rounds[0]['maxn'], nsq, kq, nsq, self.rounds[0]['sbase']))
@@ -815,19 +939,20 @@ class TeamGen(codegen.Gen):
             B('  STOP = %s;' % self.ref(self.stop))
             # keep the sinks on this side of the barrier (it is no scheduling barrier for plain arithmetic)
             for n in self.pre_sinks[b]:
-                if g.ty[n] == 'f' and g.nodes[n][0] not in LEAF:
+                if g.ty[n] == 'f' and g.nodes[n][0] not in LEAF and n not in self.stage0[b]:
                     B('  asm volatile("" :: "v"(%s));' % self.ref(n))
             pre_x = [i for i, n in enumerate(self.xdot) if self.xdot_owner[i] == b and n not in self.post]
             for i in pre_x:
                 emit_node(self.xdot[i], self.have[b] if b else None)
             if self.exp[b] or pre_x:
-                B('  if (lane == 0) {')
+                B('  if (CITW_LANE0) {')
                 for n in self.exp[b]:
-                    B('    g_x[%d] = %s;' % (self.xslot[n], ('%s ? 1.0 : 0.0' % self.ref(n)) if g.ty[n] == 'b' else self.ref(n)))
+                    if n not in self.stage0[b]:
+                        B('    g_x[%d] = %s;' % (self.xslot[n], ('%s ? 1.0 : 0.0' % self.ref(n)) if g.ty[n] == 'b' else self.ref(n)))
                 for i in pre_x:
                     B('    g_f[0][stage][%d] = %s;' % (i, self.ref(self.xdot[i])))
                 B('  }')
-            ns0 = len(self.rounds[0]['searches'])
+            ns0 = n_search(self.rounds[0])
             R0 = self.rounds[0]
 
             def wait_searches(me):
@@ -848,7 +973,7 @@ class TeamGen(codegen.Gen):
                 B('  citw_lookup2d_part<%d, %d, CITW_L2_SHARE>(0, L[0][0], g_out0, lane);' % (len(self.rounds[0]['L2']), k))
                 B('#endif')
             if b == 3 and self.h1d is not None and self.l2_helpers and SHARE_1D:
-                n1 = len(self.rounds[0]['L1'])
+                n1 = n_l1(self.rounds[0])
                 B('#if CITW_L1_SHARE(%d) > 1   /* 16 lanes per episode: the second pass of the 1-D interpolation, beside wave 1 */' % n1)
                 wait_searches(b)
                 B('  citw_lookup1d_part<%d, 1, 2>(0, L[0][1], g_out0, lane);' % n1)
@@ -856,22 +981,14 @@ class TeamGen(codegen.Gen):
             if b != 0 and b == self.h1d:
                 B('  /* ---- the 1-D interpolation pass of round 1, taken over from wave 0 */')
                 R0_ = self.rounds[0]
-                B('#if CITW_GROUP_LANES == 64 && CITW_SPEC_LOOKUP')
-                B('  citw_iflag_wait(7, %s);   /* the look-up inputs are in g_in[0] */' % SEQ)
-                B('  citw_lookup1d<%d>(0, L[%d][1], g_out0, lane);   /* on the interval indices of the previous evaluation ... */' % (len(R0_['L1']), R0_['tidx']))
-                B('  citw_iflag_wait(0, %s);   /* ... which wave 0 has verified by now */' % SEQ)
-                B('  if ((unsigned)__builtin_amdgcn_readfirstlane((int)g_smiss) == (unsigned)__builtin_amdgcn_readfirstlane((int)(%s)))' % SEQ)
-                B('    citw_lookup1d<%d>(0, L[%d][1], g_out0, lane);   /* (rare) an interval changed: once more on the repaired indices */' % (len(R0_['L1']), R0_['tidx']))
-                B('#else')
                 wait_searches(b)
                 if self.l2_helpers and SHARE_1D:
-                    n1 = len(self.rounds[0]['L1'])
+                    n1 = n_l1(self.rounds[0])
                     B('  citw_lookup1d_part<%d, 0, CITW_L1_SHARE(%d)>(0, L[0][1], g_out0, lane);   /* (16 lanes per episode: wave 3 takes the second pass) */' % (n1, n1))
                 else:
-                    B('  citw_lookup1d<%d>(0, L[0][1], g_out0, lane);' % len(self.rounds[0]['L1']))
-                B('#endif')
+                    B('  citw_lookup1d<%d>(0, L[0][1], g_out0, lane);' % n_l1(self.rounds[0]))
             B('  %s;' % TM(0))
-            B('  __syncthreads();   /* B1: look-up results (g_out0) and exchanged values (g_x) are visible to every wave */')
+            B('  CITW_TEAM_BARRIER();   /* B1: look-up results (g_out0) and exchanged values (g_x) are visible to every wave */')
             after_b1[0] = True
             B('  %s;' % TM(1))
             done_rounds.add(0)
@@ -900,17 +1017,19 @@ class TeamGen(codegen.Gen):
                             continue
                         assert self.task_wave[d] != b and d in self.pub, (t, d)
                         q, k = self.pub[d]
+                        src = 'g_y[%d]' % self.yslot[d]
                         if pwaited.get(q, 0) < k:
-                            B('  citw_pflag_wait(%d, (%s) * 16u + %du);' % (q, SEQ, k))
+                            # flag and value in ONE poll (the value's load is issued behind the flag's: one LDS round trip on a hit)
+                            src = 'citw_pflag_wait_load(%d, (%s) * 16u + %du, &g_y[%d])' % (q, SEQ, k, self.yslot[d])
                             pwaited[q] = k
                         if g.ty[d] == 'b':
-                            B('  const bool b%d = g_y[%d] != 0.0;' % (d, self.yslot[d]))
+                            B('  const bool b%d = %s != 0.0;' % (d, src))
                         else:
-                            B('  const double v%d = g_y[%d];' % (d, self.yslot[d]))
+                            B('  const double v%d = %s;' % (d, src))
                         emitted.add(d)
                     emit_node(t)
                     if t in self.pub:
-                        B('  if (lane == 0) g_y[%d] = %s;' % (self.yslot[t], ('%s ? 1.0 : 0.0' % self.ref(t)) if g.ty[t] == 'b' else self.ref(t)))
+                        B('  if (CITW_LANE0) g_y[%d] = %s;' % (self.yslot[t], ('%s ? 1.0 : 0.0' % self.ref(t)) if g.ty[t] == 'b' else self.ref(t)))
                         B('  citw_pflag_raise(%d, (%s) * 16u + %du);' % (b, SEQ, self.pub[t][1]))
             elif self.post_sinks[b]:
                 B('  /* ---- share of this wave in the glue behind the look-ups */')
@@ -918,7 +1037,7 @@ class TeamGen(codegen.Gen):
                     emit_node(n)
             post_x = [i for i, n in enumerate(self.xdot) if self.xdot_owner[i] == b and n in self.post]
             if post_x:
-                B('  if (lane == 0) {')
+                B('  if (CITW_LANE0) {')
                 for i in post_x:
                     B('    g_f[0][stage][%d] = %s;' % (i, self.ref(self.xdot[i])))
                 B('  }')
@@ -926,12 +1045,12 @@ class TeamGen(codegen.Gen):
             if dws:
                 for k in dws:
                     emit_node(self.dw_out[k])
-                B('  if (major && lane == 0) {')
+                B('  if (major && CITW_LANE0) {')
                 for k in dws:
                     B('    g_dw[0][%d] = %s;' % (k, self.ref(self.dw_out[k])))
                 B('  }')
             B('  %s;' % TM(2))
-            B('  __syncthreads();   /* B2: all derivatives of this stage are in g_f */')
+            B('  CITW_TEAM_BARRIER();   /* B2: all derivatives of this stage are in g_f */')
             B('  %s;' % TM(3))
             B('  return STOP;')
             B('}')
@@ -965,7 +1084,7 @@ class TeamGen(codegen.Gen):
             text = re.sub(r'\bg_m\[(\d+)\]', r'g_m[CITW_MROW(\1)]', text)
             text = re.sub(r'\bg_x\[(\d+)\]', r'g_x[CITW_XOFF + \1]', text)
             text = re.sub(r'\bg_y\[(\d+)\]', r'g_y[CITW_YOFF + \1]', text)
-            text = re.sub(r'\b(citw_search<[^>]*>|citw_search_part<[^>]*>|citw_lookup2d<\d+>|citw_lookup2d_part<[^>]*>|citw_lookup1d<\d+>|citw_lookup1d_part<[^>]*>)\(0, ', r'\1(CITW_TROW, ', text)
+            text = re.sub(r'\b(citw_spec_pre<[^>]*>|citw_spec_tail<[^>]*>|citw_search<[^>]*>|citw_search_part<[^>]*>|citw_lookup2d<\d+>|citw_lookup2d_part<[^>]*>|citw_lookup1d<\d+>|citw_lookup1d_part<[^>]*>)\(0, ', r'\1(CITW_TROW, ', text)
             text = text.replace('const int lane = threadIdx.x & 63;', 'const int lane = CITW_LANE;')
             return text
 

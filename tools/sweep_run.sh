@@ -5,10 +5,10 @@ O=$R/gpurun_out/${1:-sweep}
 mkdir -p $O
 cd $R
 : > $O/ab.txt
-for rep in 1 2; do
-  timeout 120 python tools/ab.py 150 >> $O/ab.txt 2>> $O/err.txt
+for rep in $(seq ${REPS:-2}); do
+  timeout ${TMO:-120} python tools/ab.py 150 >> $O/ab.txt 2>> $O/err.txt
   for t in $(cat tools/sweep_libs.txt); do
-    SERL_LIB=$R/serl_amd/csrc/libserl_amd_$t.so timeout 120 python tools/ab.py 150 >> $O/ab.txt 2>> $O/err.txt
+    SERL_LIB=$R/serl_amd/csrc/libserl_amd_$t.so timeout ${TMO:-120} python tools/ab.py 150 >> $O/ab.txt 2>> $O/err.txt
   done
 done
 cat $O/ab.txt | sed 's/.*libserl_amd_//' | cut -c1-110
