@@ -23,7 +23,7 @@
 
 // Timing experiments (never in a shipped build): CITW_ABLATE_MASK -- team wavefronts that skip their part of the evaluation
 // (rollout_team.inc); CITW_ABLATE_LOOK -- look-up passes that return at once (1: index searches, 2: 2-D, 4: 1-D, 8: the
-// precomputed lanes); CITW_NO_BARRIER -- the evaluation's two workgroup barriers left out.  Any of them freezes the state.
+// precomputed lanes); CITW_NO_BARRIER -- the evaluation's workgroup barriers left out (1: B1, 2: B2, 3: both).  Any of them freezes the state.
 #ifndef CITW_ABLATE_MASK
 #define CITW_ABLATE_MASK 0
 #endif
@@ -40,11 +40,9 @@
 #if CITW_ABLATE_LOOK & 64
 #define sincos(a, s, c) (*(s) = (a) * 0.5, *(c) = 1.0 - (a))
 #endif
-#if CITW_NO_BARRIER
-#define CITW_TEAM_BARRIER() ((void)0)
-#else
 #define CITW_TEAM_BARRIER() __syncthreads()
-#endif
+#define CITW_TEAM_BARRIER1() do { if (!(CITW_NO_BARRIER & 1)) __syncthreads(); } while (0)      // B1 / B2 of the generated team code
+#define CITW_TEAM_BARRIER2() do { if (!(CITW_NO_BARRIER & 2)) __syncthreads(); } while (0)
 
 // Lanes that work for ONE episode.  64: the wavefront is the episode (rollout_wave.inc, rollout_team.inc).  32: two
 // episodes per wavefront, lanes 0-31 / 32-63 (rollout_half.inc) -- the scalar "glue" of the model costs an instruction
@@ -289,6 +287,21 @@ static __device__ __forceinline__ void citw_pflag_wait(int q, unsigned seq)
   seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);
   if (CITW_ABLATE_LOOK & 512) return;
   while ((int)(__hip_atomic_load(&g_pflag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) CITW_POLL_PAUSE();
+}
+
+// lane k's copy of a per-lane double, for every lane (k wave-uniform): two v_readlane_b32
+#ifndef CITW_STATE_BCAST
+#define CITW_STATE_BCAST 0      // 1: single-episode team kernels read the states of an evaluation from the lanes that combined them (gen/..._team.inc).
+                                // Measured slower (r03 sweep 29: 18.38 against 18.12 us per env step; the states then live in SGPR pairs: 67 scalar spills for 39)
+#endif
+#ifndef CITW_LIBM_DIRECT
+#define CITW_LIBM_DIRECT 0      // 1: ... and libm calls whose arguments are states are made by the lanes that hold those states (no argument slots).
+                                // Measured slower as well (sweep 30: 18.38 against 18.15)
+#endif
+static __device__ __forceinline__ double citw_bcast(const double v, const int k)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
 }
 
 // Flag and value in ONE poll: the value's load is issued right behind the flag's (the LDS operations of a wavefront complete in

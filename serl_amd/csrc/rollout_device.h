@@ -159,15 +159,12 @@ struct SerlNoSync { __device__ __forceinline__ void operator()(int, int) const {
 // The actor wavefront of a team runs beside the wavefronts that integrate the model (rollout_team.inc); the hardware
 // barrier counts every wavefront of the workgroup, so it executes the step's `per_step` barriers too -- spread evenly
 // over the pieces of its forward pass, so that it is early at every one of them and never holds the team up.
-#ifndef CITW_NO_BARRIER
-#define CITW_NO_BARRIER 0       // (timing experiments: citation_wave.h)
-#endif
 struct SerlBarrierCredit {
   int done, per_step;
   __device__ __forceinline__ void operator()(int piece, int n)
   {
     const int target = per_step * (piece + 1) / n;
-    while (done < target) { if (!CITW_NO_BARRIER) __builtin_amdgcn_s_barrier(); ++done; }
+    while (done < target) { __builtin_amdgcn_s_barrier(); ++done; }
   }
 };
 
@@ -179,7 +176,7 @@ struct SerlBarrierCreditPart {
   __device__ __forceinline__ void operator()(int piece, int n)
   {
     const int target = lo + (hi - lo) * (piece + 1) / n;
-    while (base.done < target) { if (!CITW_NO_BARRIER) __builtin_amdgcn_s_barrier(); ++base.done; }
+    while (base.done < target) { __builtin_amdgcn_s_barrier(); ++base.done; }
   }
 };
 

@@ -52,7 +52,7 @@ IMPORT_COST = float(os.environ.get('CITW_TEAM_IMPORT_COST', 0.0))         # unit
 # initial load per wave behind B1 (round 1, K = 4: the wave that hands the pow chain over needed a bias of 100 units; with two
 # wavefronts per SIMD the hardware evens that out and no bias measures best)
 POST_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_POST_BIAS', '0').split(',') if v]
-PRE_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_PRE_BIAS', '0').split(',') if v]        # initial load per wave in front of B1 (negative: the wave takes more; wave 3 shares its SIMD with the mostly parked actor wavefront)
+PRE_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_PRE_BIAS', '0,0,0,-100').split(',') if v]        # initial load per wave in front of B1 (negative: the wave takes more; wave 3 shares its SIMD with the mostly parked actor wavefront)
 AFFINITY_POST = float(os.environ.get('CITW_TEAM_AFFINITY_POST', 0.0))
 SHARE_LIBM = int(os.environ.get('CITW_TEAM_SHARE_LIBM', 1))           # 1: every libm call is made by one wave, the others read the result (flag hand-over)
 SPREAD_IN = int(os.environ.get('CITW_TEAM_SPREAD_INPUTS', 0))         # 1: EVERY round-1 input cone runs on a helper; wave 0 waits for their input flags (g_iflag), then looks up
@@ -780,13 +780,31 @@ class TeamGen(codegen.Gen):
                 for j in calls:
                     if j in self.call_guard:
                         emit_node(self.call_guard[j][0])     # the condition under which this call's result is used at all
+                lo = self.calls_of[b].index(calls[0])
+                assert [self.calls_of[b].index(j) for j in calls] == list(range(lo, lo + len(calls)))
+                keys = [self.libm_calls[j][0] for j in calls]
+                direct = (len(set(k_[0] for k_ in keys)) == 1 and keys[0][0] != 'pow' and not any(j in self.call_guard for j in calls)
+                          and all(g.nodes[k_[1]][0] == 'in' and g.nodes[k_[1]][1] == 'X' for k_ in keys) and len(set(g.nodes[k_[1]][2] for k_ in keys)) == len(keys))
+                if direct:
+                    # every argument IS a state: lane i of XL holds state i (the ODE5 combination this wavefront has just made), so the
+                    # lanes of those states make the calls at once -- no trip through g_xs and the argument slots in front of the chain
+                    # every other wavefront waits for
+                    fn = keys[0][0]
+                    B('#if CITW_GROUP_LANES == 64 && CITW_LIBM_DIRECT')
+                    B('  {')
+                    B('    const int j_ = %s-1;' % ''.join('lane == %d ? %d : ' % (g.nodes[k_[1]][2], i_) for i_, k_ in enumerate(keys)))
+                    B('    double r0_ = 0.0, r1_ = 0.0;')
+                    B('    if (j_ >= 0) {')
+                    B('      %s;' % ('sincos(XL, &r0_, &r1_)' if fn == 'sincos' else 'r0_ = %s(XL)' % fn))
+                    B('      g_m[%d][2 * (%d + j_)] = r0_; g_m[%d][2 * (%d + j_) + 1] = r1_;' % (b, lo, b, lo))
+                    B('    }')
+                    B('  }')
+                    B('#else')
                 B('  if (CITW_LANE0) {')
                 for j in calls:
                     B('    g_m[%d][%d] = %s;' % (b, 48 + self.calls_of[b].index(j), self.ref(self.libm_calls[j][0][1])))
                 B('  }')
                 B('  {')
-                lo = self.calls_of[b].index(calls[0])
-                assert [self.calls_of[b].index(j) for j in calls] == list(range(lo, lo + len(calls)))
                 B('    const int l_ = lane - %d;' % lo)
                 B('    const double a_ = g_m[%d][48 + (lane >= %d && lane < %d ? lane : %d)];' % (b, lo, lo + len(calls), lo))
                 B('    double r0_ = 0.0, r1_ = 0.0;')
@@ -806,6 +824,8 @@ class TeamGen(codegen.Gen):
                     i = k
                 B('    if (l_ >= 0 && l_ < %d) { g_m[%d][2 * lane] = r0_; g_m[%d][2 * lane + 1] = r1_; }' % (len(calls), b, b))
                 B('  }')
+                if direct:
+                    B('#endif')
                 made.update(calls)
                 if raise_flag:
                     B('  citw_flag_raise(%d, %s);' % (b, SEQ))
@@ -935,7 +955,7 @@ class TeamGen(codegen.Gen):
                 if sp is not None:
                     B('#endif')
 
-            B('static __device__ CITW_EVAL_INLINE double citw_%s_team_eval_w%d(const int stage, const double T, const unsigned TICK, const unsigned FSEQ)' % (V, b))
+            B('static __device__ CITW_EVAL_INLINE double citw_%s_team_eval_w%d(const int stage, const double T, const unsigned TICK, const unsigned FSEQ, const double XL)' % (V, b))
             B('{')
             B('  const CitwSearch (*S)[64] = g_S; const CitwLookup (*L)[2][64] = g_L;')
             B('  const bool major = stage == 0;')
@@ -1112,7 +1132,7 @@ class TeamGen(codegen.Gen):
                 else:
                     B('  citw_lookup1d<%d>(0, L[0][1], g_out0, lane);' % n_l1(self.rounds[0]))
             B('  %s;' % TM(0))
-            B('  CITW_TEAM_BARRIER();   /* B1: look-up results (g_out0) and exchanged values (g_x) are visible to every wave */')
+            B('  CITW_TEAM_BARRIER1();   /* B1: look-up results (g_out0) and exchanged values (g_x) are visible to every wave */')
             after_b1[0] = True
             B('  %s;' % TM(1))
             done_rounds.add(0)
@@ -1174,7 +1194,7 @@ class TeamGen(codegen.Gen):
                     B('    g_dw[0][%d] = %s;' % (k, self.ref(self.dw_out[k])))
                 B('  }')
             B('  %s;' % TM(2))
-            B('  CITW_TEAM_BARRIER();   /* B2: all derivatives of this stage are in g_f */')
+            B('  CITW_TEAM_BARRIER2();   /* B2: all derivatives of this stage are in g_f */')
             B('  %s;' % TM(3))
             B('  return STOP;')
             B('}')
@@ -1189,8 +1209,17 @@ class TeamGen(codegen.Gen):
                 decl = []
                 for arr, pre in (('g_xs', 'xs_'), ('g_cmd', 'cm_')):
                     ks = sorted({int(k) for k in _re.findall(r'\b%s\[wv\]\[(\d+)\]' % arr, rest)})
+                    if arr == 'g_xs' and ks:
+                        # one episode per team: lane i of XL holds state i (the ODE5 combination every wavefront has just made):
+                        # v_readlane instead of the store -> load round trip through g_xs at the top of every evaluation
+                        decl.append('#if CITW_GROUP_LANES == 64 && CITW_STATE_BCAST')
+                        for k in ks:
+                            decl.append('  const double %s%d = citw_bcast(XL, %d);' % (pre, k, k))
+                        decl.append('#else')
                     for k in ks:
                         decl.append('  const double %s%d = %s[wv][%d];' % (pre, k, arr, k))
+                    if arr == 'g_xs' and ks:
+                        decl.append('#endif')
                     rest = _re.sub(r'\b%s\[wv\]\[(\d+)\]' % arr, lambda m: '%s%s' % (pre, m.group(1)), rest)
                 ks = sorted({int(k) for k in _re.findall(r'\bg_ro\[(\d+)\]', rest)})
                 for k in ks:
@@ -1215,11 +1244,11 @@ class TeamGen(codegen.Gen):
         for b in range(K - 1, -1, -1):
             P(function(b))
         P('/* wave-uniform dispatch: each wavefront of the team executes exactly one of the parts and its two barriers */')
-        P('static __device__ __forceinline__ double citw_%s_team_eval(const int wave, const int stage, const double T, const unsigned TICK, const unsigned FSEQ)' % V)
+        P('static __device__ __forceinline__ double citw_%s_team_eval(const int wave, const int stage, const double T, const unsigned TICK, const unsigned FSEQ, const double XL)' % V)
         P('{')
         for b in range(K - 1):
-            P('  if (wave == %d) return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ);' % (b, V, b))
-        P('  return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ);' % (V, K - 1))
+            P('  if (wave == %d) return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ, XL);' % (b, V, b))
+        P('  return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ, XL);' % (V, K - 1))
         P('}')
         ks = sorted(self.kslot.items(), key=lambda kv: kv[1])
         if ks:
