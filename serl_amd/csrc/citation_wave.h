@@ -294,13 +294,22 @@ static __device__ __forceinline__ void citw_pflag_wait(int q, unsigned seq)
 #define CITW_STATE_BCAST 0      // 1: single-episode team kernels read the states of an evaluation from the lanes that combined them (gen/..._team.inc).
                                 // Measured slower (r03 sweep 29: 18.38 against 18.12 us per env step; the states then live in SGPR pairs: 67 scalar spills for 39)
 #endif
+// issue priority of a wavefront while it makes libm calls the other wavefronts wait for (0: leave it alone)
+#ifndef CITW_LIBM_PRIO_LEVEL
+#define CITW_LIBM_PRIO_LEVEL 1      // (r03 sweep 32: 18.04 -> 17.93 us per env step; level 3 the same)
+#endif
+#define CITW_LIBM_PRIO(up) do { if (CITW_LIBM_PRIO_LEVEL) __builtin_amdgcn_s_setprio((up) ? CITW_LIBM_PRIO_LEVEL : 0); } while (0)
 #ifndef CITW_LIBM_DIRECT
 #define CITW_LIBM_DIRECT 0      // 1: ... and libm calls whose arguments are states are made by the lanes that hold those states (no argument slots).
                                 // Measured slower as well (sweep 30: 18.38 against 18.15)
 #endif
 static __device__ __forceinline__ double citw_bcast(const double v, const int k)
 {
+#if CITW_STATE_BCAST == 2      // through the LDS crossbar (ds_bpermute): no scalar registers, no store in front of the load
+  const int lo = __builtin_amdgcn_ds_bpermute(k * 4, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(k * 4, __double2hiint(v));
+#else
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+#endif
   return __hiloint2double(hi, lo);
 }
 

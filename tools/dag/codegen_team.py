@@ -775,6 +775,7 @@ class TeamGen(codegen.Gen):
                     return
                 assert len(self.calls_of[b]) <= 16
                 B('  /* ---- libm calls this wave makes for the team: one lane per call, results in g_m[%d] */' % b)
+                B('  CITW_LIBM_PRIO(1);')
                 for j in calls:
                     emit_node(self.libm_calls[j][0][1])
                 for j in calls:
@@ -829,6 +830,7 @@ class TeamGen(codegen.Gen):
                 made.update(calls)
                 if raise_flag:
                     B('  citw_flag_raise(%d, %s);' % (b, SEQ))
+                    B('  CITW_LIBM_PRIO(0);')
                     B('  __builtin_amdgcn_sched_barrier(0);     /* nothing of what follows may be scheduled in front of the hand-over */')
 
             made = set()
@@ -1023,6 +1025,7 @@ class TeamGen(codegen.Gen):
                         B('    g_in[0][%d] = %s;' % (k, self.ref(n)))
                 B('  }')
                 B('  citw_flag_raise(%d, %s);' % (b, SEQ))
+                B('  CITW_LIBM_PRIO(0);')
                 B('  __builtin_amdgcn_sched_barrier(0);     /* nothing of what follows may be scheduled in front of the hand-over */')
                 if self.own_lk is not None:
                     R0_ = self.rounds[0]
