@@ -25,6 +25,14 @@ CONST_DIV = int(os.environ.get('CITW_CONST_DIV', 1))      # 1: divisions by lite
 
 LOOKUPS = ('l2d', 'l1d')
 
+# ---- lazy select operands (find_gates): knobs and the cost table of the estimate
+GATES = int(os.environ.get('CITW_TEAM_GATES', os.environ.get('CITW_GATES', 1)))   # 1: cones that only the unselected operands of selects on ONE condition need run under that condition
+GATE_MIN = float(os.environ.get('CITW_TEAM_GATE_MIN', 8))                        # ... if they cost at least this much (units)
+GATE_CW = dict(div=11, sqrt=15, sel=3, unord=2, table3=120)
+GATE_FN = ('sc_sin', 'sc_cos', 'sin', 'cos', 'tan', 'exp', 'log10', 'log', 'atan', 'pow')
+GATE_LEAF = ('cf', 'ci', 'in', 'in_i', 'true', 'false')
+
+
 
 def hexf(bits):
     x = symex.b2f(bits)
@@ -248,6 +256,86 @@ class Gen:
                 self.outslot[e['node']] = (R['oarr'], R['obase2'] + k)
             for k, e in enumerate(R['L1']):
                 self.outslot[e['node']] = (R['oarr'], 64 + R['obase1'] + k)
+        self.find_gates()
+
+    # ---- lazy select operands ------------------------------------------------------------------------------------------------
+    def find_gates(self):
+        """The model computes both operands of every Switch block: the landing-gear legs (three 35-node contact models with
+        divisions and square roots), the ISA stratosphere branch, icing terms ... -- a fifth of the glue feeds only operands
+        that the trimmed flight condition never selects.  For a condition c and a polarity p, ex(c, p) is the largest set of
+        nodes ALL of whose users are in the set or are selects on c that take the node as their p-operand: nothing outside
+        reads them unless c == p.  Such a set is emitted inside `if (c == p) { ... }` (a wave-uniform branch in the single-
+        episode kernels, an exec-masked region with a skip branch in the lane-group kernels); the selects themselves stay.
+        Values and operation order are untouched: the skipped operand is the one the select discards."""
+        g = self.g
+        self.gate, self.gate_nodes, self.cold = {}, {}, set()
+        if not GATES or not getattr(self, 'use_gates', True):
+            return
+        users = collections.defaultdict(list)
+        for n in self.order:
+            for c in build_dag.children(g, n):
+                users[c].append(n)
+        rootset = set(self.roots)
+        sels = collections.defaultdict(list)
+        for n in self.order:
+            if g.nodes[n][0] == 'sel':
+                sels[g.nodes[n][1]].append(n)
+        gateable = lambda m: g.nodes[m][0] not in GATE_LEAF + LOOKUPS and g.nodes[m][0] not in GATE_FN and m not in self.libm_slot
+        cands = []
+        for c in sels:
+            for pol, idx in (('T', 2), ('F', 3)):
+                seeds = [g.nodes[s_][idx] for s_ in sels[c]]
+                cone, st = set(), list(seeds)
+                while st:
+                    m = st.pop()
+                    if m in cone or not gateable(m):
+                        continue
+                    cone.add(m)
+                    st.extend(build_dag.children(g, m))
+                ex = set(cone)
+
+                def ok_user(m, u):
+                    if u in ex:
+                        return True
+                    ku = g.nodes[u]
+                    return ku[0] == 'sel' and ku[1] == c and ku[idx] == m and ku[5 - idx] != m
+                changed = True
+                while changed:
+                    changed = False
+                    for m in list(ex):
+                        if m == c or m in rootset or m == self.stop or not all(ok_user(m, u) for u in users[m]):
+                            ex.discard(m); changed = True
+                w = sum(2 * GATE_CW.get(g.nodes[m][0], 1) for m in ex)
+                if ex and w >= GATE_MIN:
+                    cands.append((w, c, pol, ex))
+        # Which conditions does the trimmed flight condition leave closed?  Only those gates are worth a branch (the gear-down
+        # cone, 243 nodes, is open whenever the gear command is 0: gating it would only cost); nested sets: the heaviest closed
+        # one takes the node.  Correctness never depends on this choice.
+        try:
+            import interp, math
+            import numpy as np
+            src = interp.pysrc(g, self.res[1]['outs'], 'ev_all').rsplit('\n', 1)[0] + '\n    return locals()'
+            ns = dict(math=math, safe=interp.safe, sc_sin=interp.sc_sin, sc_cos=interp.sc_cos, fdiv=interp.fdiv, bitsf=interp.bitsf, fbits=interp.fbits,
+                      l2d=interp.l2d, l1d=interp.l1d, table3=interp.table3)
+            exec(src, ns)
+            data = {'nominal': 'h2000_v90'}.get(self.variant, self.variant)
+            z = np.load(os.path.join(build_dag.ROOT, 'serl_amd', 'data', 'citation_%s.npz' % data))
+            loc = ns['ev_all']([float(x) for x in z['x0']], [0.0] * 10, [float(x) for x in z['dw0'][:29]], [0.0] * 12, 0.0, 0,
+                               [float(x) for x in z['ro']], int(z['ro_base']) >> 3, [float(x) for x in z['t3']])
+        except Exception as e:      # (no data file for the variant: no gates)
+            print('find_gates: trimmed condition not evaluated (%s)' % e, file=sys.stderr)
+            return
+        for w, c, pol, ex in sorted(cands, key=lambda t: (-t[0], t[1], t[2])):
+            if bool(loc['v%d' % c]) == (pol == 'T'):
+                continue            # open in trimmed flight
+            mine = set(m for m in ex if m not in self.gate)
+            if sum(2 * GATE_CW.get(g.nodes[m][0], 1) for m in mine) < GATE_MIN:
+                continue
+            for m in mine:
+                self.gate[m] = (c, pol)
+            self.gate_nodes[(c, pol)] = mine
+            self.cold |= mine
+
 
     def closure_all(self, n):
         out, st = set(), [n]
@@ -424,7 +512,7 @@ class Gen:
             R = self.inv_round
             for n in R['ins']:
                 emit_node(n)
-            P('  if (lane == 0) {')
+            P('  if (CITW_LANE0) {')
             for k, n in enumerate(R['ins']):
                 P('    g_in[wv][%d] = %s;' % (k, self.ref(n)))
             P('  }')
@@ -439,7 +527,7 @@ class Gen:
         for n in self.inv_slot:
             emit_node(n)
         if self.inv_slot:
-            P('  if (lane == 0) {')
+            P('  if (CITW_LANE0) {')
             for n, k in self.inv_slot.items():
                 P('    g_inv[wv][%d] = %s;' % (k, ('%s ? 1.0 : 0.0' % self.ref(n)) if g.ty[n] == 'b' else self.ref(n)))
             P('  }')
@@ -530,12 +618,45 @@ class Gen:
                 P(self.inv_load(n))
                 emitted.add(n)
 
+        def emit_gated(m0):
+            """the not yet emitted part of gate (c, pol) that m0 needs, in one conditional block; what it reads from outside first"""
+            import re as _re
+            c, pol = self.gate[m0]
+            exk = self.gate_nodes[(c, pol)]
+            need, st = set(), [m0]
+            while st:
+                m = st.pop()
+                if m in need or m in emitted or m not in exk:
+                    continue
+                need.add(m)
+                st.extend(build_dag.children(g, m))
+            R = [m for m in self.order if m in need]
+            emit_node(c)
+            for r in R:
+                for ch in build_dag.children(g, r):
+                    if ch not in exk and ch not in emitted and g.nodes[ch][0] not in GATE_LEAF:
+                        emit_node(ch)
+            body = []
+            for r in R:
+                mt = _re.match(r'^  const (double|bool|long long) (\w+) = (.*);$', self.stmt(r))
+                assert mt, self.stmt(r)
+                P('  %s %s = %s;' % (mt.group(1), mt.group(2), {'double': '0.0', 'bool': 'false', 'long long': '0'}[mt.group(1)]))
+                body.append('    %s = %s;' % (mt.group(2), mt.group(3)))
+                emitted.add(r)
+            P('  if (%s%s) {   /* only the selects on this condition read these */' % ('' if pol == 'T' else '!', self.ref(c)))
+            for line in body:
+                P(line)
+            P('  }')
+
         def emit_node(n):
             # iterative post-order over un-emitted children
             stack = [(n, False)]
             while stack:
                 m, done = stack.pop()
                 if m in emitted:
+                    continue
+                if m in self.gate and not done:
+                    emit_gated(m)
                     continue
                 if done:
                     emitted.add(m)
@@ -564,7 +685,7 @@ class Gen:
                 emit_node(arg)
             for j in sorted(self.call_guard):
                 emit_node(self.call_guard[j][0])         # the condition under which call j's result is used at all
-            P('  if (lane == 0) {')
+            P('  if (CITW_LANE0) {')
             for j, ((fn, arg, prm), outs) in enumerate(self.libm_calls):
                 P('    g_in[wv][%d] = %s;' % (j, self.ref(arg)))
             P('  }')
@@ -598,7 +719,7 @@ class Gen:
             for n in R['ins']:
                 emit_node(n)
             P('  CITW_T(%d);' % (4 * r))
-            P('  if (lane == 0) {')
+            P('  if (CITW_LANE0) {')
             for k, n in enumerate(R['ins']):
                 P('    g_in[wv][%d] = %s;' % (k, self.ref(n)))
             P('  }')
@@ -629,7 +750,7 @@ class Gen:
         P('  /* ---- derivatives */')
         for i, n in enumerate(self.xdot):
             emit_node(n)
-        P('  if (lane == 0) {')
+        P('  if (CITW_LANE0) {')
         for i, n in enumerate(self.xdot):
             P('    g_f[wv][stage][%d] = %s;' % (i, self.ref(n)))
         P('  }')
@@ -639,7 +760,7 @@ class Gen:
         P('    STOP = %s;' % self.ref(self.stop))
         for k, n in sorted(self.dw_out.items()):
             emit_node(n)
-        P('    if (lane == 0) {')
+        P('    if (CITW_LANE0) {')
         for k, n in sorted(self.dw_out.items()):
             if g.nodes[n] != ('in', 'DW', k):
                 P('      g_dw[wv][%d] = %s;' % (k, self.ref(n)))

@@ -67,8 +67,6 @@ SPREAD_MIN = float(os.environ.get('CITW_TEAM_SPREAD_MIN', 0))         # with SPR
 SIMD_PAIRS = int(os.environ.get('CITW_TEAM_SIMD_PAIRS', 0))            # 1: the balancer counts the load of a SIMD (waves b and b + 4 share one) instead of a wave's
 ACTOR_UNITS = float(os.environ.get('CITW_TEAM_ACTOR_UNITS', 550))     # the actor wavefront (wave index K) as load on the SIMD it shares, units per evaluation
 ACTOR_POST = float(os.environ.get('CITW_TEAM_ACTOR_POST', 0))
-GATES = int(os.environ.get('CITW_TEAM_GATES', 1))                      # 1: cones that only the unselected operands of selects on ONE condition need are computed under that condition (lazy select operands)
-GATE_MIN = float(os.environ.get('CITW_TEAM_GATE_MIN', 8))             # ... if they cost at least this much (units)
 COLD_COST = float(os.environ.get('CITW_TEAM_COLD_COST', 1.0))        # balancer: cost factor of gated nodes that the trimmed flight condition does not execute
 SPEC = int(os.environ.get('CITW_TEAM_SPEC', 1))                        # 1: emit the merged descriptor row + the precomputed look-up lanes of wave 0 (citw_spec_pre / citw_spec_tail; compiled in with -DCITW_SPEC_LOOKUP=1)
 STAGE0 = int(os.environ.get('CITW_TEAM_STAGE0', 1))                    # 1: glue that depends on the command vector alone runs in the first of the six evaluations only (its look-up inputs / exchanged values keep their LDS slots)
@@ -104,85 +102,6 @@ class TeamGen(codegen.Gen):
         self.K = waves or TEAM_WAVES
         super().__init__(variant, split_chain=bool(SPLIT_CHAIN and self.K > 2), **kw)
         self.EW = min(ENGINE_WAVE, self.K - 1) if self.chain_round is not None else 0     # the wavefront that walks the later look-up rounds
-        self.find_gates()
-
-    # ---- lazy select operands ------------------------------------------------------------------------------------------------
-    def find_gates(self):
-        """The model computes both operands of every Switch block: the landing-gear legs (three 35-node contact models with
-        divisions and square roots), the ISA stratosphere branch, icing terms ... -- a fifth of the glue feeds only operands
-        that the trimmed flight condition never selects.  For a condition c and a polarity p, ex(c, p) is the largest set of
-        nodes ALL of whose users are in the set or are selects on c that take the node as their p-operand: nothing outside
-        reads them unless c == p.  Such a set is emitted inside `if (c == p) { ... }` (a wave-uniform branch in the single-
-        episode kernels, an exec-masked region with a skip branch in the lane-group kernels); the selects themselves stay.
-        Values and operation order are untouched: the skipped operand is the one the select discards."""
-        g = self.g
-        self.gate, self.gate_nodes, self.cold = {}, {}, set()
-        if not GATES:
-            return
-        users = collections.defaultdict(list)
-        for n in self.order:
-            for c in build_dag.children(g, n):
-                users[c].append(n)
-        rootset = set(self.roots)
-        sels = collections.defaultdict(list)
-        for n in self.order:
-            if g.nodes[n][0] == 'sel':
-                sels[g.nodes[n][1]].append(n)
-        gateable = lambda m: g.nodes[m][0] not in LEAF + LOOKUPS and g.nodes[m][0] not in FN and m not in self.libm_slot
-        cands = []
-        for c in sels:
-            for pol, idx in (('T', 2), ('F', 3)):
-                seeds = [g.nodes[s_][idx] for s_ in sels[c]]
-                cone, st = set(), list(seeds)
-                while st:
-                    m = st.pop()
-                    if m in cone or not gateable(m):
-                        continue
-                    cone.add(m)
-                    st.extend(build_dag.children(g, m))
-                ex = set(cone)
-
-                def ok_user(m, u):
-                    if u in ex:
-                        return True
-                    ku = g.nodes[u]
-                    return ku[0] == 'sel' and ku[1] == c and ku[idx] == m and ku[5 - idx] != m
-                changed = True
-                while changed:
-                    changed = False
-                    for m in list(ex):
-                        if m == c or m in rootset or m == self.stop or not all(ok_user(m, u) for u in users[m]):
-                            ex.discard(m); changed = True
-                w = sum(2 * CW.get(g.nodes[m][0], 1) for m in ex)
-                if ex and w >= GATE_MIN:
-                    cands.append((w, c, pol, ex))
-        # Which conditions does the trimmed flight condition leave closed?  Only those gates are worth a branch (the gear-down
-        # cone, 243 nodes, is open whenever the gear command is 0: gating it would only cost); nested sets: the heaviest closed
-        # one takes the node.  Correctness never depends on this choice.
-        try:
-            import interp, math
-            import numpy as np
-            src = interp.pysrc(g, self.res[1]['outs'], 'ev_all').rsplit('\n', 1)[0] + '\n    return locals()'
-            ns = dict(math=math, safe=interp.safe, sc_sin=interp.sc_sin, sc_cos=interp.sc_cos, fdiv=interp.fdiv, bitsf=interp.bitsf, fbits=interp.fbits,
-                      l2d=interp.l2d, l1d=interp.l1d, table3=interp.table3)
-            exec(src, ns)
-            data = {'nominal': 'h2000_v90'}.get(self.variant, self.variant)
-            z = np.load(os.path.join(build_dag.ROOT, 'serl_amd', 'data', 'citation_%s.npz' % data))
-            loc = ns['ev_all']([float(x) for x in z['x0']], [0.0] * 10, [float(x) for x in z['dw0'][:29]], [0.0] * 12, 0.0, 0,
-                               [float(x) for x in z['ro']], int(z['ro_base']) >> 3, [float(x) for x in z['t3']])
-        except Exception as e:      # (no data file for the variant: no gates)
-            print('find_gates: trimmed condition not evaluated (%s)' % e, file=sys.stderr)
-            return
-        for w, c, pol, ex in sorted(cands, key=lambda t: (-t[0], t[1], t[2])):
-            if bool(loc['v%d' % c]) == (pol == 'T'):
-                continue            # open in trimmed flight
-            mine = set(m for m in ex if m not in self.gate)
-            if sum(2 * CW.get(g.nodes[m][0], 1) for m in mine) < GATE_MIN:
-                continue
-            for m in mine:
-                self.gate[m] = (c, pol)
-            self.gate_nodes[(c, pol)] = mine
-            self.cold |= mine
 
     def closure(self, sinks, within):
         out, st = set(), list(sinks)
