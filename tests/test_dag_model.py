@@ -94,3 +94,34 @@ def test_constant_divisions_are_proved_correctly_rounded(variant):
     C = int(m * (1 << 53))
     q = Fraction(X, C) * (1 << (52 if X >= C else 53))
     assert abs((q - int(q)) - Fraction(1, 2)) < Fraction(1, 10 ** 15)
+
+
+@pytest.mark.parametrize('variant', ['nominal', 'ice', 'gust'])
+def test_gated_cones_are_read_only_through_their_selects(variant):
+    """Lazy select operands (tools/dag/codegen.py find_gates): a node emitted under `if (c == p)` may be read ONLY by nodes of the
+    same gate or by a select on c that takes it as its p-operand (and not as the other one) -- checked here on the DAG,
+    independently of the analysis that built the sets.  Gates never hold a root, a look-up, a libm result or their own
+    condition."""
+    import codegen, build_dag
+    gen = codegen.Gen(variant)
+    g = gen.g
+    assert gen.gate_nodes, 'no gates found for %s' % variant
+    users = {}
+    for n in gen.order:
+        for c in build_dag.children(g, n):
+            users.setdefault(c, []).append(n)
+    roots = set(gen.roots) | {gen.stop}
+    total = 0
+    for (c, pol), nodes in gen.gate_nodes.items():
+        idx = 2 if pol == 'T' else 3
+        assert c not in nodes
+        for m in nodes:
+            total += 1
+            assert gen.gate[m] == (c, pol)
+            assert m not in roots and g.nodes[m][0] not in ('l2d', 'l1d') + codegen.GATE_FN + codegen.GATE_LEAF and m not in gen.libm_slot
+            for u in users.get(m, []):
+                if u in nodes:
+                    continue
+                t = g.nodes[u]
+                assert t[0] == 'sel' and t[1] == c and t[idx] == m and t[5 - idx] != m, (variant, c, pol, m, u, t[:4])
+    assert total >= 100            # (nominal: 188 of 1 086 nodes)
