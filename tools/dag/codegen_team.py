@@ -57,9 +57,10 @@ AFFINITY_POST = float(os.environ.get('CITW_TEAM_AFFINITY_POST', 0.0))
 SHARE_LIBM = int(os.environ.get('CITW_TEAM_SHARE_LIBM', 1))           # 1: every libm call is made by one wave, the others read the result (flag hand-over)
 SPREAD_IN = int(os.environ.get('CITW_TEAM_SPREAD_INPUTS', 0))         # 1: EVERY round-1 input cone runs on a helper; wave 0 waits for their input flags (g_iflag), then looks up
 L2_WAVES = [int(x) for x in os.environ.get('CITW_TEAM_L2_WAVES', '6,4,5').split(',')]           # the helper waves that take 2-D passes 1, 2, 3
-SEARCH_WAVES = [int(x) for x in os.environ.get('CITW_TEAM_SEARCH_WAVES', '1,3').split(',')]   # the helper waves that take search passes 1 (and 2)
+SEARCH_WAVES = [int(x) for x in os.environ.get('CITW_TEAM_SEARCH_WAVES', '1,4').split(',')]   # the helper waves that take search passes 1 (and 2)
 SEARCH_AT = float(os.environ.get('CITW_TEAM_SEARCH_AT', 1.0))         # where in a helper's own glue (fraction of its sinks) its shared search pass sits (1.0: behind all of it)
 SHARE_SEARCH = int(os.environ.get('CITW_TEAM_SHARE_SEARCH', 1))    # 1: ... and the passes of round 1's index search with the helper waves SEARCH_WAVES (on the lightly loaded waves 1 and 3: four per team 26.8 -> 25.5 us; on waves 2 and 4, which also interpolate: 28.4)
+SHARE_1D_WAVE = int(os.environ.get('CITW_TEAM_SHARE_1D_WAVE', 3))   # ... this helper
 SHARE_1D = int(os.environ.get('CITW_TEAM_SHARE_1D', 1))            # 1: ... and the second pass of the 1-D interpolation (16 lanes per episode) runs on wave 3 beside wave 1's first
 SHARE_2D = int(os.environ.get('CITW_TEAM_SHARE_2D', 1))            # 1: with several episodes per team (lane groups) the passes of round 1's 2-D interpolation are shared with helper waves 2, 4, 6 (CITW_L2_SHARE)
 OFFLOAD_1D = int(os.environ.get('CITW_TEAM_OFFLOAD_1D', 1))          # 1: the 1-D interpolation pass of round 1 runs on helper wave 1 (after wave 0's index search, by flag) beside wave 0's 2-D pass
@@ -68,6 +69,8 @@ SIMD_PAIRS = int(os.environ.get('CITW_TEAM_SIMD_PAIRS', 0))            # 1: the 
 ACTOR_UNITS = float(os.environ.get('CITW_TEAM_ACTOR_UNITS', 550))     # the actor wavefront (wave index K) as load on the SIMD it shares, units per evaluation
 ACTOR_POST = float(os.environ.get('CITW_TEAM_ACTOR_POST', 0))
 COLD_COST = float(os.environ.get('CITW_TEAM_COLD_COST', 1.0))        # balancer: cost factor of gated nodes that the trimmed flight condition does not execute
+LIBM_WAVE = {kv.split(':')[0]: int(kv.split(':')[1]) for kv in os.environ.get('CITW_TEAM_LIBM_WAVE', '').split(',') if ':' in kv}     # libm function -> the helper that makes its calls (default: the least loaded one)
+TWO_PASS = int(os.environ.get('CITW_TEAM_TWO_PASS', 1))                 # 1: a helper computes what needs no foreign libm result before its first flag wait, node by node
 SPEC = int(os.environ.get('CITW_TEAM_SPEC', 1))                        # 1: emit the merged descriptor row + the precomputed look-up lanes of wave 0 (citw_spec_pre / citw_spec_tail; compiled in with -DCITW_SPEC_LOOKUP=1)
 STAGE0 = int(os.environ.get('CITW_TEAM_STAGE0', 1))                    # 1: glue that depends on the command vector alone runs in the first of the six evaluations only (its look-up inputs / exchanged values keep their LDS slots)
 OWN_LOOKUPS = int(os.environ.get('CITW_TEAM_OWN_LOOKUPS', 0))          # 1: the helper that computes a look-up input also searches / interpolates the (1-D) tables keyed on it: wave 0 never waits for it
@@ -271,6 +274,13 @@ class TeamGen(codegen.Gen):
             helpers = list(range(1, K))
             for f, calls in sorted(groups.items(), key=lambda kv: (-gcost(kv[0]), kv[0])):
                 b = min(helpers, key=lambda q: (load[q] + simd_extra(q, load) + (0.01 * load[q] if SIMD_PAIRS else 0.0), q))
+                # sincos of the five angles feeds ~300 nodes in front of B1: every helper waits for it right at its start.  Its
+                # producer is the wavefront that shares its SIMD with the (mostly parked) actor wavefront -- wave 3: the body
+                # runs at the speed of a lone wavefront (r03 sweep 36: 17.97 -> 17.72 us per env step; on waves 1 / 4 / 5: 17.97 - 18.1)
+                if f == 'sincos' and 'sincos' not in LIBM_WAVE and K >= 5:
+                    b = 3
+                if f in LIBM_WAVE and 0 < LIBM_WAVE[f] < K:
+                    b = LIBM_WAVE[f]          # (experiments: CITW_TEAM_LIBM_WAVE=sincos:3,tan:1)
                 load[b] += gcost(f)
                 for j in calls:
                     give(b, j)
@@ -995,6 +1005,18 @@ class TeamGen(codegen.Gen):
             foreign = lambda n: any(m in shared and self.row_slot[m][0] != b for m in self.closure([n], self.S0))
             order = sorted(self.pre_sinks[b], key=lambda n: (foreign(n), self.pre_sinks[b].index(n))) if shared else self.pre_sinks[b]
             search_at = int(len(order) * SEARCH_AT) if (b in SEARCH_WAVES and self.l2_helpers and SHARE_SEARCH and SEARCH_AT < 1.0) else -1
+            if shared and TWO_PASS and b != 0:
+                # first everything of this wave's share that needs no libm result of ANOTHER wavefront (node by node, not sink by
+                # sink: the cones of the later sinks hold plenty of it), then the rest behind the first flag wait
+                dep = {}
+                for m in self.order:
+                    if m in self.have[b] or m in shared:
+                        dep[m] = (m in shared and self.row_slot[m][0] != b) or any(dep.get(c, False) for c in build_dag.children(g, m))
+                early = [m for m in self.order if m in self.have[b] and not dep[m] and m not in emitted and m not in self.gate
+                         and m not in shared and g.nodes[m][0] not in LEAF + LOOKUPS
+                         and any(dep.get(u, False) for u in self.users[m] if u in self.have[b])]
+                for m in early:       # (only the frontier towards the libm-dependent part: the rest comes with its sinks above)
+                    emit_node(m, self.have[b])
             for kk, n in enumerate(order):
                 if kk == search_at:
                     emit_search_share(b)
@@ -1038,7 +1060,7 @@ class TeamGen(codegen.Gen):
                 wait_searches(b)
                 B('  citw_lookup2d_part<%d, %d, CITW_L2_SHARE>(0, L[0][0], g_out0, lane);' % (len(self.rounds[0]['L2']), k))
                 B('#endif')
-            if b == 3 and self.h1d is not None and self.l2_helpers and SHARE_1D:
+            if b == SHARE_1D_WAVE and self.h1d is not None and self.l2_helpers and SHARE_1D:
                 n1 = n_l1(self.rounds[0])
                 B('#if CITW_L1_SHARE(%d) > 1   /* 16 lanes per episode: the second pass of the 1-D interpolation, beside wave 1 */' % n1)
                 wait_searches(b)

@@ -11,7 +11,8 @@ tag = sys.argv[1]
 extra = sys.argv[2:]
 B.build()                                   # the product objects
 objdir = os.path.join(B.CSRC, 'build')
-objs = [os.path.join(objdir, u.replace('.hip', '.o')) for u in B.UNITS if u != 'rollout_team_nominal.hip']
+units = os.environ.get('EXP_UNITS', 'rollout_team_nominal.hip').split(',')      # e.g. EXP_UNITS=rollout_team_nominal.hip,rollout_team4_nominal.hip
+objs = [os.path.join(objdir, u.replace('.hip', '.o')) for u in B.UNITS if u not in units]
 inc = 'gen/citation_nominal_team_%s.inc' % tag
 flags = list(B.FLAGS) + extra
 if os.environ.get('EXP_DROP_LICM'):            # A/B: let the machine LICM hoist the model's f64 literals out of the stage loop
@@ -19,12 +20,15 @@ if os.environ.get('EXP_DROP_LICM'):            # A/B: let the machine LICM hoist
     del flags[i - 1:i + 1]
 if os.path.exists(os.path.join(B.CSRC, inc)):
     flags.append('-DCITW_TEAM_INC="%s"' % inc)
-obj = os.path.join(objdir, 'rollout_team_nominal_%s.o' % tag)
-r = subprocess.run([B.HIPCC] + flags + ['-c', os.path.join(B.CSRC, 'rollout_team_nominal.hip'), '-o', obj], capture_output=True, text=True)
-if r.returncode:
-    sys.exit(r.stderr[-3000:])
+mine = []
+for u in units:
+    obj = os.path.join(objdir, u.replace('.hip', '_%s.o' % tag))
+    r = subprocess.run([B.HIPCC] + flags + ['-c', os.path.join(B.CSRC, u), '-o', obj], capture_output=True, text=True)
+    if r.returncode:
+        sys.exit(r.stderr[-3000:])
+    mine.append(obj)
 lib = os.path.join(B.CSRC, 'libserl_amd_%s.so' % tag)
-r = subprocess.run([B.HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib, obj] + objs, capture_output=True, text=True)
+r = subprocess.run([B.HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + mine + objs, capture_output=True, text=True)
 if r.returncode:
     sys.exit(r.stderr[-3000:])
 print(lib)
