@@ -313,26 +313,15 @@ static __device__ __forceinline__ double citw_bcast(const double v, const int k)
   return __hiloint2double(hi, lo);
 }
 
-// Flag and value in ONE poll: the value's load is issued right behind the flag's (the LDS operations of a wavefront complete in
-// order, so a value loaded behind a raised flag is the published one) -- one LDS round trip on a hit instead of two
-#ifndef CITW_POLL_LOAD
-#define CITW_POLL_LOAD 1
-#endif
+// A flag wait that returns the first value behind the flag.  The value is loaded BEHIND an acquire load of the raised flag.
+// (Round 3 tried to issue the value's load in the same poll iteration as the flag's, both relaxed, for one LDS round trip on a hit:
+// nothing orders two relaxed loads of different addresses, the compiler may issue the value's first -- with a flag that is raised
+// right behind its data (the early libm flag) a consumer then read the slot BEFORE the data: NaNs in the first launch of a
+// process, found by tools/repeat_check.py.  It had measured +-0.05 us anyway.)
 static __device__ __forceinline__ double citw_poll_load_(const unsigned *flag, unsigned seq, const double *p)
 {
-#if CITW_POLL_LOAD
-  unsigned f;
-  double v;
-  do {
-    f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  } while ((int)(f - seq) < 0);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  return v;
-#else
   while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) CITW_POLL_PAUSE();
   return *p;
-#endif
 }
 static __device__ __forceinline__ double citw_pflag_wait_load(int q, unsigned seq, const double *p)
 {

@@ -70,6 +70,7 @@ ACTOR_UNITS = float(os.environ.get('CITW_TEAM_ACTOR_UNITS', 550))     # the acto
 ACTOR_POST = float(os.environ.get('CITW_TEAM_ACTOR_POST', 0))
 COLD_COST = float(os.environ.get('CITW_TEAM_COLD_COST', 1.0))        # balancer: cost factor of gated nodes that the trimmed flight condition does not execute
 LIBM_WAVE = {kv.split(':')[0]: int(kv.split(':')[1]) for kv in os.environ.get('CITW_TEAM_LIBM_WAVE', '').split(',') if ':' in kv}     # libm function -> the helper that makes its calls (default: the least loaded one)
+EARLY_FLAG = int(os.environ.get('CITW_TEAM_EARLY_FLAG', 0))             # 1: the first libm function group of a wavefront is announced by a flag of its own (g_flag[8 + q]).  OFF: one episode per team +-0, four per team 23.2 -> 22.5 us BUT NaNs in the first launch of a process with lane groups (tools/repeat_check.py; cause not found)
 TWO_PASS = int(os.environ.get('CITW_TEAM_TWO_PASS', 1))                 # 1: a helper computes what needs no foreign libm result before its first flag wait, node by node
 SPEC = int(os.environ.get('CITW_TEAM_SPEC', 1))                        # 1: emit the merged descriptor row + the precomputed look-up lanes of wave 0 (citw_spec_pre / citw_spec_tail; compiled in with -DCITW_SPEC_LOOKUP=1)
 STAGE0 = int(os.environ.get('CITW_TEAM_STAGE0', 1))                    # 1: glue that depends on the command vector alone runs in the first of the six evaluations only (its look-up inputs / exchanged values keep their LDS slots)
@@ -576,6 +577,16 @@ class TeamGen(codegen.Gen):
             for jl, j in enumerate(calls):
                 for which, node in self.libm_calls[j][1].items():
                     self.row_slot[node] = (q, 2 * jl + (0 if which == 'r0' else 1))
+        # A wavefront that makes calls of several functions (sincos + tan) runs their bodies one after the other: the results of
+        # the FIRST group are announced by a flag of their own, g_flag[8 + q], as soon as they are stored
+        self.flag_of = {}
+        for q, calls in self.calls_of.items():
+            fns = [self.libm_calls[j][0][0] for j in calls]
+            multi = EARLY_FLAG and len(set(fns)) > 1
+            for j in calls:
+                early = multi and self.libm_calls[j][0][0] == fns[0]
+                for node in self.libm_calls[j][1].values():
+                    self.flag_of[node] = (8 + q) if early else q
         shared = self.shared_libm
         # does anybody but the owner read a wave's libm results in front of B1?  (then the owner raises its flag)
         # sequence number of the evaluation for the hand-over flags: FSEQ counts the team's env steps (NOT the model clock TICK: the
@@ -672,9 +683,10 @@ class TeamGen(codegen.Gen):
                         t = g.nodes[m]
                         if m in shared:
                             q, sl = self.row_slot[m]
-                            if q != b and q not in waited and not after_b1[0]:
-                                B('  const double v%d = citw_flag_wait_load(%d, %s, &g_m[%d][%d]);   /* libm results of wave %d */' % (m, q, SEQ, q, sl, q))
-                                waited.add(q)
+                            fl = self.flag_of.get(m, q)
+                            if q != b and fl not in waited and q not in waited and not after_b1[0]:
+                                B('  const double v%d = citw_flag_wait_load(%d, %s, &g_m[%d][%d]);   /* libm results of wave %d */' % (m, fl, SEQ, q, sl, q))
+                                waited.add(fl)
                             else:
                                 B('  const double v%d = g_m[%d][%d];' % (m, q, sl))
                             continue
@@ -738,7 +750,7 @@ class TeamGen(codegen.Gen):
                 B('    const int l_ = lane - %d;' % lo)
                 B('    const double a_ = g_m[%d][48 + (lane >= %d && lane < %d ? lane : %d)];' % (b, lo, lo + len(calls), lo))
                 B('    double r0_ = 0.0, r1_ = 0.0;')
-                i, first = 0, True
+                i, first, first_done = 0, True, 0
                 while i < len(calls):
                     (fn, arg, prm) = self.libm_calls[calls[i]][0]
                     k = i
@@ -749,10 +761,20 @@ class TeamGen(codegen.Gen):
                         gd = self.call_guard[calls[i]]
                         cond = '(l_ == %d && %s%s)' % (i, '' if gd[1] else '!', self.ref(gd[0]))
                     call = {'sincos': 'sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = pow(a_, %s)' % hexf(prm)}.get(fn, 'r0_ = %s(a_)' % fn)
+                    early = any(self.flag_of.get(nd, b) == 8 + b for nd in self.libm_calls[calls[i]][1].values())
+                    if early and first:
+                        # the first function's results leave at once, behind a flag of their own
+                        B('    if %s { %s; }' % (cond, call))
+                        B('    if (l_ >= %d && l_ < %d) { g_m[%d][2 * lane] = r0_; g_m[%d][2 * lane + 1] = r1_; }   /* (zeros for a call its guard skipped: the slot is never left unwritten) */' % (i, k, b, b))
+                        B('    citw_flag_raise(%d, %s);' % (8 + b, SEQ))
+                        first_done = k
+                        i = k
+                        first = True
+                        continue
                     B('    %sif %s { %s; }' % ('' if first else 'else ', cond, call))
                     first = False
                     i = k
-                B('    if (l_ >= 0 && l_ < %d) { g_m[%d][2 * lane] = r0_; g_m[%d][2 * lane + 1] = r1_; }' % (len(calls), b, b))
+                B('    if (l_ >= %d && l_ < %d) { g_m[%d][2 * lane] = r0_; g_m[%d][2 * lane + 1] = r1_; }' % (first_done, len(calls), b, b))
                 B('  }')
                 if direct:
                     B('#endif')

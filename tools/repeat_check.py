@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Run-to-run reproducibility on the GPU box: python tools/repeat_check.py [runs] [E]   (SERL_LIB selects the .so)
+the same rollout `runs` times; every fitness / length must be bit-identical between runs (a race shows up as a difference)."""
+import os, sys, json
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import serl_amd
+from serl_amd import refsignals
+eng = serl_amd.RolloutEngine(0)
+w = torch.from_numpy(np.load('tests/golden/actors.npz')['serl50'])
+spec = serl_amd.NetSpec(7, 3, 32, 3, 'tanh')
+ref = refsignals.tabulate(*refsignals.base_reference(20), 20)
+runs = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+E = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+moe = np.arange(E) % len(w)
+base, bad = None, 0
+for r in range(runs):
+    out = eng.rollout(w, spec, moe, ref, t_max=20)
+    fit = out['fitness'].cpu().numpy().copy(); ln = out['length_steps'].cpu().numpy().copy()
+    if base is None:
+        base = (fit, ln)
+    elif not (np.array_equal(fit, base[0], equal_nan=False) and np.array_equal(ln, base[1])):
+        bad += 1
+        d = np.flatnonzero(~((fit == base[0]) & (ln == base[1])))
+        print('run', r, 'differs in episodes', d[:10].tolist(), fit[d[:3]].tolist(), base[0][d[:3]].tolist())
+print(os.environ.get('SERL_LIB', 'default'), json.dumps({'runs': runs, 'episodes': E, 'runs_that_differ': bad, 'nan_in_first_run': int(np.isnan(base[0]).sum())}))
