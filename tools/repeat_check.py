@@ -7,8 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import serl_amd
 from serl_amd import refsignals
 eng = serl_amd.RolloutEngine(0)
-w = torch.from_numpy(np.load('tests/golden/actors.npz')['serl50'])
-spec = serl_amd.NetSpec(7, 3, 32, 3, 'tanh')
+TAG = os.environ.get('AB_ACTORS', 'serl50')          # serl50 (H = 32) | serl10 (H = 72: the actor streams its weights) | td3 (H = 96)
+w = torch.from_numpy(np.load('tests/golden/actors.npz')[TAG])
+spec = {'serl50': serl_amd.NetSpec(7, 3, 32, 3, 'tanh'), 'serl10': serl_amd.NetSpec(7, 3, 72, 3, 'tanh'),
+        'td3': serl_amd.NetSpec(7, 3, 96, 3, 'relu')}[TAG]
 ref = refsignals.tabulate(*refsignals.base_reference(20), 20)
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 150
