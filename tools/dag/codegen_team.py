@@ -280,7 +280,7 @@ class TeamGen(codegen.Gen):
                 # runs at the speed of a lone wavefront (r03 sweep 36: 17.97 -> 17.72 us per env step; on waves 1 / 4 / 5: 17.97 - 18.1)
                 if f == 'sincos' and 'sincos' not in LIBM_WAVE and K >= 5:
                     b = 3
-                if f in LIBM_WAVE and 0 < LIBM_WAVE[f] < K:
+                if f in LIBM_WAVE and 0 <= LIBM_WAVE[f] < K:
                     b = LIBM_WAVE[f]          # (experiments: CITW_TEAM_LIBM_WAVE=sincos:3,tan:1)
                 load[b] += gcost(f)
                 for j in calls:
@@ -985,6 +985,10 @@ class TeamGen(codegen.Gen):
                     B('  citw_search_range<%d, %d, %d, %d>(CITW_TROW, S[%d], lane);' % (max(sr[1] for sr in R0_['searches'][ns_:]), ns_, nso_, R0_['sbase'], R0_['tidx']))
                     B('  citw_lookup1d_range<%d, %d>(CITW_TROW, L[%d][1], g_out0, lane);' % (n1_, n1o_, R0_['tidx']))
             if shared:
+                # (the wavefront of the handed-over chain raises ITS flag once, behind the look-up input: calls of another function
+                # made later would hide behind a flag that is already up -- r03 sweep 40, `tan` forced onto it: a stale result)
+                assert not (b == self.P and not self.spread and any(j not in made for j in self.calls_of.get(b, []))), \
+                    'wave %d hands its look-up input over and cannot make further libm calls for the team' % b
                 libm_phase_shared()
             else:
                 libm_phase(self.have[b])
