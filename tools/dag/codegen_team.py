@@ -70,7 +70,7 @@ ACTOR_UNITS = float(os.environ.get('CITW_TEAM_ACTOR_UNITS', 550))     # the acto
 ACTOR_POST = float(os.environ.get('CITW_TEAM_ACTOR_POST', 0))
 COLD_COST = float(os.environ.get('CITW_TEAM_COLD_COST', 1.0))        # balancer: cost factor of gated nodes that the trimmed flight condition does not execute
 LIBM_WAVE = {kv.split(':')[0]: int(kv.split(':')[1]) for kv in os.environ.get('CITW_TEAM_LIBM_WAVE', '').split(',') if ':' in kv}     # libm function -> the helper that makes its calls (default: the least loaded one)
-EARLY_FLAG = int(os.environ.get('CITW_TEAM_EARLY_FLAG', 0))             # 1: the first libm function group of a wavefront is announced by a flag of its own (g_flag[8 + q]).  OFF: one episode per team +-0, four per team 23.2 -> 22.5 us BUT NaNs in the first launch of a process with lane groups (tools/repeat_check.py; cause not found)
+EARLY_FLAG = int(os.environ.get('CITW_TEAM_EARLY_FLAG', 2))             # 2: the first libm function group of a wavefront (sincos in front of tan) is announced by a flag of its own, g_flag[8 + q] -- except on the wavefront of the handed-over chain (1: there too -- with lane groups that produced NaNs in the first launch of a process, r03 sweeps 39 / 41, cause not found; 0: off)
 TWO_PASS = int(os.environ.get('CITW_TEAM_TWO_PASS', 1))                 # 1: a helper computes what needs no foreign libm result before its first flag wait, node by node
 SPEC = int(os.environ.get('CITW_TEAM_SPEC', 1))                        # 1: emit the merged descriptor row + the precomputed look-up lanes of wave 0 (citw_spec_pre / citw_spec_tail; compiled in with -DCITW_SPEC_LOOKUP=1)
 STAGE0 = int(os.environ.get('CITW_TEAM_STAGE0', 1))                    # 1: glue that depends on the command vector alone runs in the first of the six evaluations only (its look-up inputs / exchanged values keep their LDS slots)
@@ -582,7 +582,7 @@ class TeamGen(codegen.Gen):
         self.flag_of = {}
         for q, calls in self.calls_of.items():
             fns = [self.libm_calls[j][0][0] for j in calls]
-            multi = EARLY_FLAG and len(set(fns)) > 1
+            multi = EARLY_FLAG and len(set(fns)) > 1 and (EARLY_FLAG == 1 or (EARLY_FLAG == 2 and q != self.P) or (EARLY_FLAG == 3 and q == self.P))
             for j in calls:
                 early = multi and self.libm_calls[j][0][0] == fns[0]
                 for node in self.libm_calls[j][1].values():
