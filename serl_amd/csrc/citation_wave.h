@@ -209,7 +209,22 @@ __shared__ unsigned long long g_tlast;
                          g_prof[(k)] += t_ - g_tlast; g_tlast = t_; } } while (0)
 __shared__ unsigned long long g_tlast1;       // same for wave 1 of the team kernels
 __shared__ unsigned long long g_tlastw[16];    // ... and for the other waves (barrier arrival / departure only)
-#if CITW_PROFILE == 2      // second profiling build: waves 4, 5, 6 report into the slots waves 1, 2, 3 use in the first
+#if CITW_PROFILE == 3      // LIGHT profile: only how long every team wavefront waits at the two barriers (slots 0 .. 6: B1, 8 .. 14: B2) -- two
+                           // clock reads and one LDS update per barrier and wavefront, ~1 % (the full phase profile costs 15 % and distorts)
+static __device__ __forceinline__ constexpr int citw_mark_k(int s) { return s == 10 || s == 15 || s == 19 ? 0 : s == 11 || s == 16 || s == 21 ? 1 : s == 12 || s == 17 || s == 24 ? 2 : s == 13 || s == 18 || s == 25 ? 3 : -1; }
+#define CITW_MARK_(w, k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+                           if ((k) == 0 || (k) == 2) g_tlastw[(w)] = t_; else if ((k) == 1) g_prof[(w)] += t_ - g_tlastw[(w)]; else if ((k) == 3) g_prof[8 + (w)] += t_ - g_tlastw[(w)]; } } while (0)
+#undef CITW_T0
+#undef CITW_T
+#define CITW_T0() ((void)0)
+#define CITW_T(k) do { if ((k) <= 3) CITW_MARK_(0, (k)); } while (0)
+#define CITW_U0() ((void)0)
+#define CITW_U(k) do { if ((k) >= 10 && (k) <= 13) CITW_MARK_(1, (k) - 10); } while (0)
+#define CITW_W0(w) ((void)0)
+#define CITW_W(w, s) do { if (citw_mark_k(s) >= 0) CITW_MARK_((w), citw_mark_k(s)); } while (0)
+#define CITW_V0(w) ((void)0)
+#define CITW_V(w, s) do { if (citw_mark_k(s) >= 0) CITW_MARK_((w), citw_mark_k(s)); } while (0)
+#elif CITW_PROFILE == 2      // second profiling build: waves 4, 5, 6 report into the slots waves 1, 2, 3 use in the first
 #define CITW_U0() ((void)0)
 #define CITW_U(k) ((void)0)
 #define CITW_W0(w) ((void)0)
