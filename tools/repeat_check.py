@@ -17,7 +17,7 @@ E = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 moe = np.arange(E) % len(w)
 base, bad = None, 0
 for r in range(runs):
-    out = eng.rollout(w, spec, moe, ref, t_max=20)
+    out = eng.rollout(w, spec, moe, ref, t_max=20, build=os.environ.get('AB_BUILD', 'h2000_v90'))
     fit = out['fitness'].cpu().numpy().copy(); ln = out['length_steps'].cpu().numpy().copy()
     if base is None:
         base = (fit, ln)
@@ -25,4 +25,4 @@ for r in range(runs):
         bad += 1
         d = np.flatnonzero(~((fit == base[0]) & (ln == base[1])))
         print('run', r, 'differs in episodes', d[:10].tolist(), fit[d[:3]].tolist(), base[0][d[:3]].tolist())
-print(os.environ.get('SERL_LIB', 'default'), json.dumps({'runs': runs, 'episodes': E, 'runs_that_differ': bad, 'nan_in_first_run': int(np.isnan(base[0]).sum())}))
+print(os.environ.get('SERL_LIB', 'default'), json.dumps({'build': os.environ.get('AB_BUILD', 'h2000_v90'), 'runs': runs, 'episodes': E, 'runs_that_differ': bad, 'nan_in_first_run': int(np.isnan(base[0]).sum())}))
