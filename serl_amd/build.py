@@ -62,5 +62,42 @@ def build(force=False, verbose=False, extra_flags=(), lib=None, tag=''):
     return LIB
 
 
+JITTER_LIB = 'libserl_amd_jitter.so'
+TEAM_UNITS = [u for u in UNITS if u.startswith('rollout_team')]
+
+
+def build_variant(lib, tag, extra_flags, units, force=False):
+    """A library next to the product: `units` recompiled with `extra_flags` (objects build/<unit><tag>.o), every other object the
+    product's own."""
+    build()
+    path = os.path.join(CSRC, lib)
+    if not force and os.path.exists(path) and all(os.path.getmtime(path) >= os.path.getmtime(d) for d in _deps() + [LIB]):
+        return path
+    objdir = os.path.join(CSRC, 'build')
+
+    def cc(unit):
+        obj = os.path.join(objdir, unit.replace('.hip', tag + '.o'))
+        r = subprocess.run([HIPCC] + FLAGS + list(extra_flags) + ['-c', os.path.join(CSRC, unit), '-o', obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for %s:\n%s' % (unit, r.stderr[-4000:]))
+        return obj
+    with ThreadPoolExecutor(max_workers=len(units)) as ex:
+        mine = list(ex.map(cc, units))
+    objs = mine + [os.path.join(objdir, u.replace('.hip', '.o')) for u in UNITS if u not in units]
+    r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', path] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n' + r.stderr[-4000:])
+    return path
+
+
+def build_jitter(force=False):
+    """TEST-ONLY library csrc/libserl_amd_jitter.so: the team kernel families compiled with -DCITW_POISON=1 -DCITW_JITTER=1
+    (citation_wave.h: LDS blackboards start as slot-naming signalling NaNs; seeded pseudo-random pauses around every hand-over
+    flag and barrier, seed from SERL_JITTER_SEED).  tests/test_gpu_rollout.py runs it against the oracle; the product never loads it."""
+    return build_variant(JITTER_LIB, '_jitter', ['-DCITW_POISON=1', '-DCITW_JITTER=1'], TEAM_UNITS, force)
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))
+    if '--jitter' in sys.argv:
+        print(build_jitter(force='--force' in sys.argv))

@@ -40,9 +40,60 @@
 #if CITW_ABLATE_LOOK & 64
 #define sincos(a, s, c) (*(s) = (a) * 0.5, *(c) = 1.0 - (a))
 #endif
+// Hand-over stress builds (test-only library libserl_amd_jitter.so, serl_amd/build.py build_jitter; never in the product):
+//   -DCITW_POISON=1   every LDS blackboard the wavefronts of a team exchange values through starts as a signalling NaN whose
+//                     payload names the slot (array << 32 | index), the interval hints as 0x5a5a5a5a: a read that is not ordered
+//                     behind its producer's write returns poison in EVERY launch, not only in the first one of a process
+//   -DCITW_JITTER=1   a pseudo-random pause (hash of seed, site, wavefront, workgroup, sequence number; 0 .. 4 k cycles, now and
+//                     then 32 k -- what a cold instruction cache does to one wavefront) in front of every flag raise, behind every
+//                     flag wait and around every barrier; the seed comes from the context (SERL_JITTER_SEED, read by
+//                     serl_ctx_create; 0 = no pauses).  A hand-over that is only right because its producer is usually early
+//                     returns poison or a stale value under some seed; tests/test_gpu_rollout.py compares with the oracle.
+#ifndef CITW_POISON
+#define CITW_POISON 0
+#endif
+#ifndef CITW_JITTER
+#define CITW_JITTER 0
+#endif
+#if CITW_JITTER
+__shared__ unsigned g_jseed;          // RolloutArgs.jitter, staged by the kernels
+__shared__ unsigned g_jsites;         // RolloutArgs.jitter_sites: which classes of sites pause (bit per class, below; diagnosis: tools/jitter_classes.py)
+// class of a site: 0 .. 6 = flag raise / wait, iflag raise / wait, pflag raise / wait, value poll; 7 .. 11 = the actor hand-over (0xa00
+// actor in front of its flag, 0xa10 team behind the action wait, 0xa20 in front of the observation flag, 0xa30 behind the ODE5
+// combination, 0xa40 behind a step of a lane-group team); 12 = the actor wavefront's barriers; 13 / 14 = in front of / behind B1; 15 / 16 = B2
+static __device__ __forceinline__ constexpr unsigned citw_jitter_class_(const unsigned site)
+{
+  return site < 0xa00u ? (site >> 8) - 1u : site < 0xac0u ? 7u + ((site >> 4) & 15u) : site < 0xb00u ? 12u : site == 0xb10u ? 13u : site == 0xb11u ? 14u : site == 0xb20u ? 15u : 16u;
+}
+static __device__ __forceinline__ void citw_jitter_(const unsigned site, const unsigned seq)
+{
+  unsigned h = g_jseed;
+  if (h == 0u || ((g_jsites >> citw_jitter_class_(site)) & 1u) == 0u) return;
+  h ^= seq * 2654435761u; h ^= site * 0x9e3779b1u; h ^= (unsigned)(threadIdx.x >> 6) * 0x85ebca6bu; h ^= (unsigned)blockIdx.x * 0xc2b2ae35u;
+  h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12; h *= 0x297a2d39u; h ^= h >> 15;
+  h = (unsigned)__builtin_amdgcn_readfirstlane((int)h);
+  if ((h & 3u) != 0u) return;                       // one site in four pauses ...
+  unsigned n = (h >> 8) & 31u;                      // ... 0 .. 31 x 128 cycles,
+  if (((h >> 2) & 63u) == 0u) n *= 8u;              // one pause in 64 eight times as long
+  for (unsigned i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(2);
+}
+#define CITW_JIT(site, seq) citw_jitter_((site), (seq))
+#else
+#define CITW_JIT(site, seq) ((void)0)
+#endif
+// LANES of one wavefront that hand values to each other through LDS -- one lane (or a few) stores, every lane loads -- are separate
+// THREADS of the language's memory model.  The hardware completes the LDS operations of a wavefront in order, but nothing tells the
+// COMPILER: round 3's early libm flag split "lanes 0 and 1 store their results" into two single-lane stores, whose addresses are
+// constants -- LLVM's load-PRE then forwarded the stored value on the storing lane's path and sank the load of every other lane into
+// the complementary path, which the structurizer places IN FRONT of the store: the other lanes read the slot before it was written
+// (first launch of a process: NaN; later: the previous evaluation's value -- profiles/r04_experiments.md, found with the poison
+// build).  A wavefront-scope fence is the ordering the code means: it emits no instruction, it makes the stores of all lanes
+// "visible before" the loads that follow.  Every lane-subset store that the same wavefront reads back is followed by one.
+#define CITW_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 #define CITW_TEAM_BARRIER() __syncthreads()
-#define CITW_TEAM_BARRIER1() do { if (!(CITW_NO_BARRIER & 1)) __syncthreads(); } while (0)      // B1 / B2 of the generated team code
-#define CITW_TEAM_BARRIER2() do { if (!(CITW_NO_BARRIER & 2)) __syncthreads(); } while (0)
+// B1 / B2 of the generated team code (FSEQ and stage are in scope there; jitter builds pause on both sides)
+#define CITW_TEAM_BARRIER1() do { if (!(CITW_NO_BARRIER & 1)) { CITW_JIT(0xb10u, FSEQ * 8u + (unsigned)stage); __syncthreads(); CITW_JIT(0xb11u, FSEQ * 8u + (unsigned)stage); } } while (0)
+#define CITW_TEAM_BARRIER2() do { if (!(CITW_NO_BARRIER & 2)) { CITW_JIT(0xb20u, FSEQ * 8u + (unsigned)stage); __syncthreads(); CITW_JIT(0xb21u, FSEQ * 8u + (unsigned)stage); } } while (0)
 
 // Lanes that work for ONE episode.  64: the wavefront is the episode (rollout_wave.inc, rollout_team.inc).  32: two
 // episodes per wavefront, lanes 0-31 / 32-63 (rollout_half.inc) -- the scalar "glue" of the model costs an instruction
@@ -267,6 +318,7 @@ static __device__ __forceinline__ constexpr int citw_mark_k(int s) { return s ==
 static __device__ __forceinline__ void citw_flag_raise(int q, unsigned seq)
 {
   seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);     // (two episodes per team: the first one's model clock counts for both)
+  CITW_JIT(0x100u + q, seq);
   if ((CITW_UNIFORM_STORE & 2) || (threadIdx.x & 63) == 0) __hip_atomic_store(&g_flag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 static __device__ __forceinline__ void citw_flag_wait(int q, unsigned seq)
@@ -276,18 +328,21 @@ static __device__ __forceinline__ void citw_flag_wait(int q, unsigned seq)
   // tolerates it cannot hang either
   if (CITW_ABLATE_LOOK & 256) return;      // (timing experiment: values "ready at once")
   while ((int)(__hip_atomic_load(&g_flag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) CITW_POLL_PAUSE();
+  CITW_JIT(0x200u + q, seq);
 }
 
 // ... and a second set for the look-up inputs a helper wavefront computes for wave 0 (spread-input partitions)
 static __device__ __forceinline__ void citw_iflag_raise(int q, unsigned seq)
 {
   seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);     // (two episodes per team: the first one's model clock counts for both)
+  CITW_JIT(0x300u + q, seq);
   if ((CITW_UNIFORM_STORE & 2) || (threadIdx.x & 63) == 0) __hip_atomic_store(&g_iflag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 static __device__ __forceinline__ void citw_iflag_wait(int q, unsigned seq)
 {
   seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);     // (two episodes per team: the first one's model clock counts for both)
   while ((int)(__hip_atomic_load(&g_iflag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) CITW_POLL_PAUSE();
+  CITW_JIT(0x400u + q, seq);
 }
 
 // ... and a third for the task graph behind the look-ups (gen/citation_<v>_team.inc): wave q announces its k-th published value
@@ -295,6 +350,7 @@ static __device__ __forceinline__ void citw_iflag_wait(int q, unsigned seq)
 static __device__ __forceinline__ void citw_pflag_raise(int q, unsigned seq)
 {
   seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);
+  CITW_JIT(0x500u + q, seq);
   if ((CITW_UNIFORM_STORE & 2) || (threadIdx.x & 63) == 0) __hip_atomic_store(&g_pflag[q], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 static __device__ __forceinline__ void citw_pflag_wait(int q, unsigned seq)
@@ -302,6 +358,7 @@ static __device__ __forceinline__ void citw_pflag_wait(int q, unsigned seq)
   seq = (unsigned)__builtin_amdgcn_readfirstlane((int)seq);
   if (CITW_ABLATE_LOOK & 512) return;
   while ((int)(__hip_atomic_load(&g_pflag[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) CITW_POLL_PAUSE();
+  CITW_JIT(0x600u + q, seq);
 }
 
 // lane k's copy of a per-lane double, for every lane (k wave-uniform): two v_readlane_b32
@@ -336,6 +393,7 @@ static __device__ __forceinline__ double citw_bcast(const double v, const int k)
 static __device__ __forceinline__ double citw_poll_load_(const unsigned *flag, unsigned seq, const double *p)
 {
   while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) CITW_POLL_PAUSE();
+  CITW_JIT(0x700u, seq);
   return *p;
 }
 static __device__ __forceinline__ double citw_pflag_wait_load(int q, unsigned seq, const double *p)
@@ -377,6 +435,7 @@ static __device__ __forceinline__ void citw_search(const int wv, const CitwSearc
 {
 #pragma unroll
   for (int base = 0; base < COUNT; base += CITW_GROUP_LANES) citw_search_pass<MAXN, COUNT, SBASE>(wv, S, lane + base);
+  CITW_WAVE_FENCE();      // the look-up lanes that follow read the indices other lanes stored
 }
 
 // The passes PART, PART + NPARTS, ... of a search round (several episodes per team: helper wavefronts take passes beside wave 0)
@@ -389,6 +448,7 @@ static __device__ __forceinline__ void citw_search_part(const int wv, const Citw
 {
 #pragma unroll
   for (int base = PART * CITW_GROUP_LANES; base < COUNT; base += NPARTS * CITW_GROUP_LANES) citw_search_pass<MAXN, COUNT, SBASE>(wv, S, lane + base);
+  CITW_WAVE_FENCE();
 }
 
 #ifndef CITW_SPEC_LOOKUP
@@ -489,6 +549,7 @@ static __device__ __forceinline__ void citw_search_range(const int wv, const Cit
 {
   static_assert(N <= CITW_GROUP_LANES, "one pass");
   citw_search_pass<MAXN, FIRST + N, SBASE>(wv, S, lane < N ? lane + FIRST : FIRST + N);
+  CITW_WAVE_FENCE();
 }
 
 template <typename OUT>
@@ -498,6 +559,7 @@ static __device__ __forceinline__ void citw_lookup2d(const int wv, const CitwLoo
 {
 #pragma unroll
   for (int base = 0; base < COUNT; base += CITW_GROUP_LANES) citw_lookup2d_pass(wv, L, out, lane + base);
+  CITW_WAVE_FENCE();      // every lane reads the results back as wave-uniform loads
 }
 
 // The passes PART, PART + NPARTS, ... of a 2-D round: with fewer lanes per episode than tables (two / four episodes per team)
@@ -510,6 +572,7 @@ static __device__ __forceinline__ void citw_lookup2d_part(const int wv, const Ci
 {
 #pragma unroll
   for (int base = PART * CITW_GROUP_LANES; base < COUNT; base += NPARTS * CITW_GROUP_LANES) citw_lookup2d_pass(wv, L, out, lane + base);
+  CITW_WAVE_FENCE();
 }
 
 template <typename OUT>
@@ -610,6 +673,7 @@ static __device__ __forceinline__ void citw_lookup1d(const int wv, const CitwLoo
 {
 #pragma unroll
   for (int base = 0; base < COUNT; base += CITW_GROUP_LANES) citw_lookup1d_pass(wv, L, out, lane + base);
+  CITW_WAVE_FENCE();
 }
 
 // 1-D tables FIRST .. FIRST + N - 1 of a round on the first N lanes of the lane group (citw_search_range; the other lanes run
@@ -619,6 +683,7 @@ static __device__ __forceinline__ void citw_lookup1d_range(const int wv, const C
 {
   static_assert(N <= CITW_GROUP_LANES && FIRST + N <= 63, "one pass, and a filler row");
   citw_lookup1d_pass(wv, L, out, lane < N ? lane + FIRST : 63);
+  CITW_WAVE_FENCE();
 }
 
 // ... and of a 1-D round (two wavefronts at most)
@@ -628,6 +693,7 @@ static __device__ __forceinline__ void citw_lookup1d_part(const int wv, const Ci
 {
 #pragma unroll
   for (int base = PART * CITW_GROUP_LANES; base < COUNT; base += NPARTS * CITW_GROUP_LANES) citw_lookup1d_pass(wv, L, out, lane + base);
+  CITW_WAVE_FENCE();
 }
 
 template <typename OUT>
@@ -726,6 +792,7 @@ static __device__ __forceinline__ bool citw_spec_tail(const int wv, const CitwSp
   const double res = (p.tq >> 24) != 0 ? a : r + a;
   const bool miss = __ballot(lane >= S0 && lane < S1 && !ok) != 0ULL;
   if (!miss && lane >= T0 && lane < T1) out[wv][(p.tq >> 16) & 255] = res;
+  CITW_WAVE_FENCE();
   return miss;
 }
 

@@ -26,6 +26,7 @@ struct RolloutArgs {
   int32_t e0, e_end;                  // team kernels: the episodes [e0, e_end) of the descriptor this launch runs (serl_rollout splits large launches)
   int32_t *queue;                     // multi-episode team kernels: device counter of the episodes handed out beyond the first one of every lane group
   int32_t q0;                         // ... the first episode of the queue (episodes [q0, e_end) are taken as lane groups finish theirs)
+  uint32_t jitter, jitter_sites;      // hand-over stress builds only (citation_wave.h, -DCITW_JITTER): seed of the pseudo-random pauses (0 = none), classes of sites that pause
 };
 
 #define DET_FN __device__ __forceinline__
@@ -159,12 +160,20 @@ struct SerlNoSync { __device__ __forceinline__ void operator()(int, int) const {
 // The actor wavefront of a team runs beside the wavefronts that integrate the model (rollout_team.inc); the hardware
 // barrier counts every wavefront of the workgroup, so it executes the step's `per_step` barriers too -- spread evenly
 // over the pieces of its forward pass, so that it is early at every one of them and never holds the team up.
+#if defined(CITW_JITTER) && CITW_JITTER      // (hand-over stress builds, citation_wave.h: the actor wavefront arrives at the step's barriers at random times)
+#define SERL_CREDIT_JIT(c) citw_jitter_(0xac0u + (unsigned)(c).done, (c).salt)
+#else
+#define SERL_CREDIT_JIT(c) ((void)0)
+#endif
 struct SerlBarrierCredit {
   int done, per_step;
+#if defined(CITW_JITTER) && CITW_JITTER
+  unsigned salt = 0;      // the env step (jitter hash only)
+#endif
   __device__ __forceinline__ void operator()(int piece, int n)
   {
     const int target = per_step * (piece + 1) / n;
-    while (done < target) { __builtin_amdgcn_s_barrier(); ++done; }
+    while (done < target) { SERL_CREDIT_JIT(*this); __builtin_amdgcn_s_barrier(); ++done; }
   }
 };
 
@@ -176,7 +185,7 @@ struct SerlBarrierCreditPart {
   __device__ __forceinline__ void operator()(int piece, int n)
   {
     const int target = lo + (hi - lo) * (piece + 1) / n;
-    while (base.done < target) { __builtin_amdgcn_s_barrier(); ++base.done; }
+    while (base.done < target) { SERL_CREDIT_JIT(base); __builtin_amdgcn_s_barrier(); ++base.done; }
   }
 };
 

@@ -287,6 +287,8 @@ int serl_ctx_create(int device, serl_ctx **out)
     }
     c->env_waves_per_block = (e = getenv("SERL_WAVES_PER_BLOCK")) ? atoi(e) : -1;
     c->env_profile = getenv("SERL_PROFILE") != nullptr;
+    c->env_jitter = (e = getenv("SERL_JITTER_SEED")) ? (unsigned)strtoul(e, nullptr, 0) : 0u;
+    c->env_jitter_sites = (e = getenv("SERL_JITTER_SITES")) ? (unsigned)strtoul(e, nullptr, 0) : ~0u;
   }
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
@@ -366,6 +368,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   a.d = *d;
   a.ro = s.blob; a.t3 = s.blob + s.n_ro; a.x0 = a.t3 + 46; a.dw0 = a.x0 + 19;
   a.dyn_dt = s.dt;
+  a.jitter = c->env_jitter; a.jitter_sites = c->env_jitter_sites;
   a.prof = nullptr;
   if (c->env_profile) {
     if (!c->prof) HIP_TRY(hipMalloc((void **)&c->prof, 32 * sizeof(unsigned long long)));
@@ -525,6 +528,7 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
   a.d.n_episodes = n_episodes;
   a.ro = s.blob; a.t3 = s.blob + s.n_ro; a.x0 = a.t3 + 46; a.dw0 = a.x0 + 19;
   a.dyn_dt = s.dt;
+  a.jitter = c->env_jitter; a.jitter_sites = c->env_jitter_sites;
   hipStream_t stream = (hipStream_t)stream_;
   if (lanes_per_wave <= 0 && serl_use_team(c, hint, n_episodes)) {
     a.lanes = 1;

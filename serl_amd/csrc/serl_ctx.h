@@ -30,6 +30,8 @@ struct serl_ctx {
   int lds_per_block = 65536;            // sharedMemPerBlockOptin
   // environment overrides, read once when the context is made (-1 = not set)
   int env_kernel = 0 /* serl_kernel_hint from SERL_KERNEL */, env_waves_per_block = -1, env_profile = 0;
+  unsigned env_jitter_sites = ~0u;      // SERL_JITTER_SITES: classes of sites that pause (citation_wave.h; all by default)
+  unsigned env_jitter = 0;              // SERL_JITTER_SEED: seed of the hand-over stress builds' pauses (libserl_amd_jitter.so; the product ignores it)
   BuildSlot slots[SERL_MAX_SLOTS];
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;

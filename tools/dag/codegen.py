@@ -325,6 +325,7 @@ class Gen:
         except Exception as e:      # (no data file for the variant: no gates)
             print('find_gates: trimmed condition not evaluated (%s)' % e, file=sys.stderr)
             return
+        self.trim_loc = loc          # every node's value in trimmed flight (tools/dag/critical_path.py: which guards are closed there)
         for w, c, pol, ex in sorted(cands, key=lambda t: (-t[0], t[1], t[2])):
             if bool(loc['v%d' % c]) == (pol == 'T'):
                 continue            # open in trimmed flight
@@ -689,6 +690,7 @@ class Gen:
             for j, ((fn, arg, prm), outs) in enumerate(self.libm_calls):
                 P('    g_in[wv][%d] = %s;' % (j, self.ref(arg)))
             P('  }')
+            P('  CITW_WAVE_FENCE();')
             P('  {')
             P('    const double a_ = g_in[wv][lane < %d ? lane : 0];' % len(self.libm_calls))
             P('    double r0_ = 0.0, r1_ = 0.0;')
@@ -708,6 +710,7 @@ class Gen:
                 j = k
             P('    if (lane < %d) { g_m[wv][2 * lane] = r0_; g_m[wv][2 * lane + 1] = r1_; }' % len(self.libm_calls))
             P('  }')
+            P('  CITW_WAVE_FENCE();   /* the lanes that made the calls stored, every lane loads the results */')
             if not self.lazy_loads:
                 for (fn, arg, prm), outs in self.libm_calls:
                     for node in outs.values():
@@ -723,6 +726,7 @@ class Gen:
             for k, n in enumerate(R['ins']):
                 P('    g_in[wv][%d] = %s;' % (k, self.ref(n)))
             P('  }')
+            P('  CITW_WAVE_FENCE();   /* (one lane may have stored the inputs alone: CITW_UNIFORM_STORE) */')
             sa = (R['maxn'], len(R['searches']), R['sbase'])
             P('#if CITW_GROUP_LANES == 64 && CITW_FUSED_LOOKUP   /* the look-up lanes verify the hints of their own index searches */')
             P('  CITW_T(%d);' % (4 * r + 1))

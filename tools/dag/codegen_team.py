@@ -746,6 +746,7 @@ class TeamGen(codegen.Gen):
                 for j in calls:
                     B('    g_m[%d][%d] = %s;' % (b, 48 + self.calls_of[b].index(j), self.ref(self.libm_calls[j][0][1])))
                 B('  }')
+                B('  CITW_WAVE_FENCE();')
                 B('  {')
                 B('    const int l_ = lane - %d;' % lo)
                 B('    const double a_ = g_m[%d][48 + (lane >= %d && lane < %d ? lane : %d)];' % (b, lo, lo + len(calls), lo))
@@ -766,6 +767,7 @@ class TeamGen(codegen.Gen):
                         # the first function's results leave at once, behind a flag of their own
                         B('    if %s { %s; }' % (cond, call))
                         B('    if (l_ >= %d && l_ < %d) { g_m[%d][2 * lane] = r0_; g_m[%d][2 * lane + 1] = r1_; }   /* (zeros for a call its guard skipped: the slot is never left unwritten) */' % (i, k, b, b))
+                        B('    CITW_WAVE_FENCE();')
                         B('    citw_flag_raise(%d, %s);' % (8 + b, SEQ))
                         first_done = k
                         i = k
@@ -776,6 +778,7 @@ class TeamGen(codegen.Gen):
                     i = k
                 B('    if (l_ >= %d && l_ < %d) { g_m[%d][2 * lane] = r0_; g_m[%d][2 * lane + 1] = r1_; }' % (first_done, len(calls), b, b))
                 B('  }')
+                B('  CITW_WAVE_FENCE();   /* the lanes that made the calls stored; every lane of this wavefront loads the results it needs (citation_wave.h) */')
                 if direct:
                     B('#endif')
                 made.update(calls)
@@ -798,6 +801,7 @@ class TeamGen(codegen.Gen):
                 for j, ((fn, arg, prm), outs) in enumerate(lst):
                     B('    g_m[wv][%d] = %s;' % (48 + j, self.ref(arg)))
                 B('  }')
+                B('  CITW_WAVE_FENCE();')
                 B('  {')
                 B('    const double a_ = g_m[wv][48 + (lane < %d ? lane : 0)];' % len(lst))
                 B('    double r0_ = 0.0, r1_ = 0.0;')
@@ -814,6 +818,7 @@ class TeamGen(codegen.Gen):
                     j = k
                 B('    if (lane < %d) { g_m[wv][2 * lane] = r0_; g_m[wv][2 * lane + 1] = r1_; }' % len(lst))
                 B('  }')
+                B('  CITW_WAVE_FENCE();')
                 for (fn, arg, prm), outs in lst:
                     for node in outs.values():
                         emitted.add(node)
@@ -842,6 +847,7 @@ class TeamGen(codegen.Gen):
                     if not (r == 0 and n in self.stage0[b]):
                         B('    g_in[%s][%d] = %s;' % (row, R['ibase'] + k, self.ref(n)))
                 B('  }')
+                B('  CITW_WAVE_FENCE();   /* (one lane may have stored the inputs alone -- CITW_UNIFORM_STORE --, the search / look-up lanes of this wavefront load them) */')
                 if r == 0:
                     B('  %s;' % TM(5))
                     if self.spread:
@@ -959,6 +965,7 @@ class TeamGen(codegen.Gen):
                         B('    g_x[%d] = %s;' % (self.xslot[n], ('%s ? 1.0 : 0.0' % self.ref(n)) if g.ty[n] == 'b' else self.ref(n)))
                 B('  }')
                 B('  }')
+                B('  CITW_WAVE_FENCE();')
             if self.spread:
                 pass          # (inputs follow the libm phase below)
             elif b == self.P:

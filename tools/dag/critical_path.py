@@ -13,6 +13,13 @@ the measured 23 us per env step; six evaluations + one ODE5 combination make an 
                     instruction count of the compiler's IEEE division / sqrt expansion; the lane-parallel phases (index
                     search, interpolation passes, the libm bodies, table3) at their INSTRUCTION counts (PHASE_INSTR below:
                     counted in the ISA of the shipped kernel, one pass serves all tables of a round) x 4 cycles.
+                    A division by a literal that tools/dag/constdiv.py proves counts 4 instructions (citw_div_const),
+                    any other the 13 of the IEEE expansion.  Reported twice: for the FULL DAG (every node, every libm
+                    body -- what an evaluation costs when every Switch block of the model is open), and for the TRIMMED
+                    flight condition (`issue_floor_trimmed_*`: without the nodes the lazy select operands skip there --
+                    codegen.find_gates -- and without the libm bodies whose guard is closed: exp, log10 at 2 000 m) --
+                    the floor of what the benchmark's episodes actually execute, and the one `issue_floor_frac` of the
+                    bench line is taken against.
   dependency floor  the longest chain of dependent operations, each at its measured dependent-issue latency
                     (tools/valu_latency.hip): no partition of the DAG over wavefronts can finish sooner.  A table look-up
                     counts with ITS OWN dependent chain -- input to the lanes, breakpoints, table values: three LDS round
@@ -22,7 +29,7 @@ the measured 23 us per env step; six evaluations + one ODE5 combination make an 
 """
 import os, sys, json, collections
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import build_dag
+import build_dag, codegen
 
 LEAF = ('cf', 'ci', 'in', 'in_i', 'true', 'false', 'undef')
 # instructions per node (VALU issue slots)
@@ -45,7 +52,8 @@ def main():
     if '--latency' in sys.argv:
         m = json.load(open(sys.argv[sys.argv.index('--latency') + 1]))
         lat.update({k: (v[1] if isinstance(v, list) else v) for k, v in m.items() if k != 'what'})
-    g, res, _ = build_dag.build(variant, fast_zero=True)
+    gen = codegen.Gen(variant)
+    g, res = gen.g, gen.res
     roots = list(res[1]['outs'].values())
     seen, stack = set(), list(roots)
     while stack:
@@ -55,8 +63,31 @@ def main():
         seen.add(n)
         stack.extend(build_dag.children(g, n))
     census = collections.Counter(g.nodes[n][0] for n in seen if g.nodes[n][0] not in LEAF)
-    glue_instr = sum(INSTR.get(op, 1) * c for op, c in census.items() if op not in LIBM + ('l2d', 'l1d', 'table3'))
+
+    def instr(n):
+        t = g.nodes[n]
+        if t[0] == 'div' and g.nodes[t[2]][0] == 'cf' and gen.const_div_ok(g.nodes[t[2]][1]):
+            return 4          # reciprocal multiply + two fma + div_fixup (citw_div_const), proved per divisor
+        return INSTR.get(t[0], 1)
+    glue = [n for n in seen if g.nodes[n][0] not in LEAF + LIBM + ('l2d', 'l1d', 'table3')]
+    const_divs = sum(1 for n in glue if g.nodes[n][0] == 'div' and instr(n) == 4)
+    glue_instr = sum(instr(n) for n in glue)
     issue_cycles = glue_instr * 4 + 4 * sum(PHASE_INSTR.values())
+    # ... and what the trimmed flight condition executes: gated nodes are skipped, guarded libm calls whose condition is closed too
+    cold = set(gen.cold) & set(glue)
+    phases_trim = dict(PHASE_INSTR)
+    closed = []
+    loc = getattr(gen, 'trim_loc', None)
+    for j, (cnode, pol) in gen.call_guard.items():
+        fn = gen.libm_calls[j][0][0]
+        if loc is not None and bool(loc['v%d' % cnode]) != bool(pol) and fn in phases_trim:
+            others = [k for k in range(len(gen.libm_calls)) if k != j and gen.libm_calls[k][0][0] == fn
+                      and not (k in gen.call_guard and bool(loc['v%d' % gen.call_guard[k][0]]) != bool(gen.call_guard[k][1]))]
+            if not others:          # (the calls of one function share a body: it is skipped only if every call of it is)
+                closed.append(fn)
+                phases_trim.pop(fn)
+    glue_instr_trim = sum(instr(n) for n in glue if n not in cold)
+    issue_cycles_trim = glue_instr_trim * 4 + 4 * sum(phases_trim.values())
     # dependent-latency weights (cycles)
     L_add, L_mul = lat['dep_add_f64'], lat['dep_mul_f64']
     W = dict(add=L_add, sub=L_add, mul=L_mul, neg=4, fabs=4, div=lat['dep_div_f64'], sqrt=lat['dep_sqrt_plus_add'] - L_add,
@@ -94,6 +125,8 @@ def main():
         n = via.get(n)
     out = dict(variant=variant, live_nodes=sum(census.values()), census=dict(census.most_common()),
                glue_instructions_min=glue_instr, issue_floor_cycles_per_eval_4_simds=issue_cycles / 4.0,
+               divisions_by_proved_literals=const_divs, glue_instructions_min_trimmed=glue_instr_trim, gated_nodes_skipped_in_trim=len(cold),
+               libm_bodies_closed_in_trim=sorted(closed), issue_floor_trimmed_cycles_per_eval_4_simds=issue_cycles_trim / 4.0,
                dependency_floor_cycles_per_eval=depth[end], critical_chain=dict(chain.most_common()),
                latencies_used={k: lat[k] for k in ('dep_add_f64', 'dep_mul_f64', 'dep_div_f64', 'dep_sqrt_plus_add', 'cmp_select_add',
                                                    'lds_roundtrip_plus_add')},
@@ -102,6 +135,7 @@ def main():
                clock_ghz=2.4)
     per_step = lambda c: (6 * c) / 2.4e3
     out['issue_floor_us_per_env_step'] = per_step(out['issue_floor_cycles_per_eval_4_simds'])
+    out['issue_floor_trimmed_us_per_env_step'] = per_step(out['issue_floor_trimmed_cycles_per_eval_4_simds'])
     out['dependency_floor_us_per_env_step'] = per_step(out['dependency_floor_cycles_per_eval'])
     print(json.dumps(out))
 

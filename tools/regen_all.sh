@@ -1,0 +1,9 @@
+#!/bin/bash
+# regenerate every committed generated kernel source (serl_amd/csrc/gen): run after any change of tools/dag/codegen*.py
+set -e
+cd "$(dirname "$0")/.."
+V="nominal ice cg_timed gust test"
+python tools/dag/codegen.py $V
+python tools/dag/codegen_team.py $V
+python tools/dag/codegen_team.py $V --waves=6 --suffix=6
+python tools/dag/codegen_lane.py nominal ice

@@ -25,4 +25,6 @@ for r in range(runs):
         bad += 1
         d = np.flatnonzero(~((fit == base[0]) & (ln == base[1])))
         print('run', r, 'differs in episodes', d[:10].tolist(), fit[d[:3]].tolist(), base[0][d[:3]].tolist())
+if os.environ.get('REPEAT_OUT'):      # the FIRST launch's results, for the caller to compare with the oracle (tests/test_gpu_rollout.py)
+    np.savez(os.environ['REPEAT_OUT'], fitness=base[0], length_steps=base[1], moe=moe)
 print(os.environ.get('SERL_LIB', 'default'), json.dumps({'build': os.environ.get('AB_BUILD', 'h2000_v90'), 'runs': runs, 'episodes': E, 'runs_that_differ': bad, 'nan_in_first_run': int(np.isnan(base[0]).sum())}))
