@@ -89,8 +89,17 @@ def evaluate_generation(pop: Sequence, rl_agent=None, *, args, mode='nominal', t
     actors = [_actor_of(a) for a in pop]
     for a in actors:
         a.eval()                                            # agent.py:83
-    spec = spec_of(actors[0])
     n_pop = len(actors)
+    if n_pop == 0 and rl_agent is None:
+        # (evaluate_generation_sharded: a rank whose member block is empty and no RL episode to fly -- nothing to launch)
+        z = np.zeros((ne, 0))
+        T0 = refsignals.n_steps_for(t_max)
+        res = PopResult(fitness=z, returns=z, smoothness=z, length_steps=z.astype(np.int32), length_t=z, cost_steps=z.astype(np.int32),
+                        pop_fitness=np.zeros(0), champion=-1, worst=-1, kernel_ms=0.0, episode_member=np.zeros(0, np.int32))
+        g = GenerationResult(pop=res, rl_episode=None, kernel_ms=0.0)
+        g.stored, g.staged = [], torch.zeros(0, T0, 2 * builds.env_dims(env_config, incremental)[0] + builds.env_dims(env_config, incremental)[1] + 3)
+        return g
+    spec = spec_of(actors[0] if actors else _actor_of(rl_agent))
     members = list(actors)
     E = n_pop * ne
     moe = np.repeat(np.arange(n_pop, dtype=np.int32), ne)
@@ -134,7 +143,7 @@ def evaluate_generation(pop: Sequence, rl_agent=None, *, args, mode='nominal', t
     pop_fitness = np.mean(fitness, axis=0)
     res = PopResult(fitness=fitness, returns=sh(ret), smoothness=sh(sm), length_steps=sh(ls),
                     length_t=sh(out['length_t'].cpu().numpy()), cost_steps=sh(out['cost_steps'].cpu().numpy()),
-                    pop_fitness=pop_fitness, champion=int(np.argmax(pop_fitness)), worst=int(np.argmin(pop_fitness)),
+                    pop_fitness=pop_fitness, champion=int(np.argmax(pop_fitness)) if n_pop else -1, worst=int(np.argmin(pop_fitness)) if n_pop else -1,
                     kernel_ms=engine.last_kernel_ms, actions=out['actions'][:E], states=out['states'][:E],
                     rewards=out['rewards'][:E], transitions=out.get('transitions'), episode_member=moe[:E])
     cs = out['cost_steps'].cpu().numpy()
@@ -164,7 +173,7 @@ def evaluate_generation(pop: Sequence, rl_agent=None, *, args, mode='nominal', t
 
 def evaluate_generation_sharded(pop: Sequence, rl_agent=None, *, args, mode='nominal', t_max=20, refs=None, rl_noise=None,
                                 engine: Optional[RolloutEngine] = None, replay_buffer=None, counters=None,
-                                store: bool = True) -> GenerationResult:
+                                store: bool = True, env_config=0, incremental=False) -> GenerationResult:
     """`evaluate_generation` with the population sharded over the ranks of the default process group (one process per GPU,
     `torch.distributed` over RCCL): rank r evaluates the contiguous member block `distributed.member_block` gives
     it, ONE all_gather brings every member's result rows to every rank, ONE more the rows of every member's stored episode
@@ -175,14 +184,16 @@ def evaluate_generation_sharded(pop: Sequence, rl_agent=None, *, args, mode='nom
     rank) this IS evaluate_generation.  The per-step traces of the population (actions / states / rewards) stay on the rank
     that flew them: `result.pop.actions` etc. are None here.
 
-    refs: None, one [T, 3] table, or [pop*num_evals (+1), T, 3] for ALL members (every rank passes the same array and uses
-    its block's rows)."""
+    refs: None, one [T, 3] table / one refsignals.ref_specs row, or [pop*num_evals (+1), T, 3] tables / [pop*num_evals (+1)]
+    spec rows for ALL members (every rank passes the same array and uses its block's rows).  A rank whose member block is empty
+    (pop < world size, or the last ranks of a population that does not divide it: distributed.member_block) flies the RL episode
+    only -- or nothing -- and contributes zero rows to both gathers."""
     import torch.distributed as dist
     from . import distributed as sd, replay
     ws = dist.get_world_size() if dist.is_initialized() else 1
     if ws == 1:
         return evaluate_generation(pop, rl_agent, args=args, mode=mode, t_max=t_max, refs=refs, rl_noise=rl_noise, engine=engine,
-                                   replay_buffer=replay_buffer, counters=counters, store=store)
+                                   replay_buffer=replay_buffer, counters=counters, store=store, env_config=env_config, incremental=incremental)
     engine = engine or default_engine()
     rk = dist.get_rank()
     ne, n_pop = int(args.num_evals), len(pop)
@@ -191,13 +202,17 @@ def evaluate_generation_sharded(pop: Sequence, rl_agent=None, *, args, mode='nom
         T_ = refsignals.n_steps_for(t_max)
         rl_noise = np.clip(args.noise_sd * np.random.randn(T_, 3), -args.noise_clip, args.noise_clip)     # the same draw on every rank
     local_refs = refs
-    if refs is not None and not (isinstance(refs, np.ndarray) and refs.dtype.names is not None):
+    rows_ = list(range(lo * ne, hi * ne)) + ([n_pop * ne] if rl_agent is not None else [])
+    if refs is not None and isinstance(refs, np.ndarray) and refs.dtype.names is not None:
+        if len(refs) > 1:                      # refsignals.ref_specs rows, one per episode: this block's (+ the RL episode's)
+            assert len(refs) == n_pop * ne + (1 if rl_agent is not None else 0), 'one reference spec per episode of the WHOLE population'
+            local_refs = refs[rows_] if rows_ else refs[:1]
+    elif refs is not None:
         r_ = torch.as_tensor(refs, dtype=torch.float64)
         if r_.dim() == 3:
-            rows = list(range(lo * ne, hi * ne)) + ([n_pop * ne] if rl_agent is not None else [])
-            local_refs = r_[rows]
+            local_refs = r_[rows_] if rows_ else r_[:1]
     g = evaluate_generation(pop[lo:hi], rl_agent, args=args, mode=mode, t_max=t_max, refs=local_refs, rl_noise=rl_noise,
-                            engine=engine, store=store, _defer_store=True)
+                            engine=engine, store=store, env_config=env_config, incremental=incremental, _defer_store=True)
     dev = engine.device
     p = g.pop
     rows = np.stack([p.fitness, p.returns, p.smoothness, p.length_t, p.length_steps.astype(np.float64), p.cost_steps.astype(np.float64)], -1)
@@ -210,7 +225,7 @@ def evaluate_generation_sharded(pop: Sequence, rl_agent=None, *, args, mode='nom
     if store:
         n_loc = hi - lo
         idx = [e for (_, e, _, _) in g.stored[:n_loc]]
-        staged = g.staged[idx] if n_loc else g.staged[:0]
+        staged = g.staged[idx] if n_loc else g.staged[:0]          # (an empty block: zero rows of the right [T, width] shape)
         steps = [n for (_, _, n, _) in g.stored[:n_loc]]
         cost = [c for (_, _, _, c) in g.stored[:n_loc]]
         allb, asteps, acost = sd.gather_stored_episodes(torch.as_tensor(staged).to(dev), steps, cost, n_pop, ws, rk)

@@ -186,46 +186,66 @@ def _gen_setup():
 
 
 def _digest(pop, rl, shared, counters, g):
-    bufs = [shared] + [a.buffer for a in pop + [rl]] + [a.critical_buffer for a in pop + [rl]]
+    agents = pop + ([rl] if rl is not None else [])
+    bufs = [shared] + [a.buffer for a in agents] + [a.critical_buffer for a in agents]
     return dict(fitness=g.pop.fitness.copy(), lengths=g.pop.length_steps.copy(), champion=g.pop.champion, counters=dict(counters),
                 lens=[len(b) for b in bufs], sums=[float(sum(float(np.sum(t[0])) + float(np.sum(t[1])) + t[3] for t in b)) for b in bufs],
-                rl_fitness=g.rl_episode.fitness)
+                rl_fitness=g.rl_episode.fitness if g.rl_episode is not None else None)
 
 
-def _gen_worker(rank, world, port, q):
+def _gen_worker(rank, world, port, q, with_rl=True):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     serl_amd, args, pop, rl, refs, noise, eng = _gen_setup()
+    if not with_rl:
+        rl, refs, noise = None, refs[:-1], None
     from serl_amd.generation import evaluate_generation_sharded
     shared, counters = _Buf(), {}
-    g = evaluate_generation_sharded(pop, rl, args=args, t_max=20, refs=refs, rl_noise=noise, engine=eng, replay_buffer=shared, counters=counters)
+    try:
+        g = evaluate_generation_sharded(pop, rl, args=args, t_max=20, refs=refs, rl_noise=noise, engine=eng, replay_buffer=shared, counters=counters)
+    except Exception:          # (a rank that dies leaves the others in a collective: tell the test at once)
+        import traceback
+        q.put((rank, {'error': traceback.format_exc()}))
+        os._exit(3)
     q.put((rank, _digest(pop, rl, shared, counters, g)))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(900)
-def test_generation_sharded_over_two_ranks_equals_single_process():
-    """evaluate_generation_sharded on two gloo ranks (population of 5: blocks 3 + 2, the RL actor's exploration episode on
-    both): the gathered fitness table, the champion, the counters and EVERY buffer (shared, per agent, critical) must come out
-    on both ranks exactly as evaluate_generation fills them in one process.  (Local evaluation = the CPU oracle behind
+@pytest.mark.parametrize('world,with_rl', [(2, True), (4, True), (4, False)])
+def test_generation_sharded_over_ranks_equals_single_process(world, with_rl):
+    """evaluate_generation_sharded on gloo ranks (population of 5; two ranks: blocks 3 + 2; FOUR ranks: blocks 2 + 2 + 1 + 0 -- a
+    rank with an EMPTY member block, which flies the RL actor's exploration episode only, or nothing at all without an RL actor):
+    the gathered fitness table, the champion, the counters and EVERY buffer (shared, per agent, critical) must come out on every
+    rank exactly as evaluate_generation fills them in one process.  (Local evaluation = the CPU oracle behind
     RolloutEngine.rollout's call shape: the sharding, the two all-gathers and the buffer order are what is under test.)"""
     serl_amd, args, pop, rl, refs, noise, eng = _gen_setup()
+    if not with_rl:
+        rl, refs, noise = None, refs[:-1], None
     shared, counters = _Buf(), {}
     g = serl_amd.evaluate_generation(pop, rl, args=args, t_max=20, refs=refs, rl_noise=noise, engine=eng, replay_buffer=shared, counters=counters)
     single = _digest(pop, rl, shared, counters, g)
-    assert single['lens'][0] == sum(single['lens'][1:7]) and single['counters']['num_episodes'] == 6
+    n_agents = 6 if with_rl else 5
+    assert single['lens'][0] == sum(single['lens'][1:1 + n_agents]) and single['counters']['num_episodes'] == n_agents
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_gen_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 31500 + (os.getpid() + 7 * world + int(with_rl)) % 2000
+    procs = [ctx.Process(target=_gen_worker, args=(r, world, port, q, with_rl)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=600) for _ in range(2))
+    got = {}
+    for _ in range(world):
+        r_, d_ = q.get(timeout=600)
+        if 'error' in d_:
+            for p in procs:
+                p.kill()
+            pytest.fail('rank %d: %s' % (r_, d_['error']))
+        got[r_] = d_
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for r in (0, 1):
+    for r in range(world):
         np.testing.assert_array_equal(got[r]['fitness'], single['fitness'])
         np.testing.assert_array_equal(got[r]['lengths'], single['lengths'])
         assert got[r]['champion'] == single['champion'] and got[r]['counters'] == single['counters']

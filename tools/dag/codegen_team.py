@@ -1065,14 +1065,15 @@ class TeamGen(codegen.Gen):
             pre_x = [i for i, n in enumerate(self.xdot) if self.xdot_owner[i] == b and n not in self.post]
             for i in pre_x:
                 emit_node(self.xdot[i], self.have[b] if b else None)
-            if self.exp[b] or pre_x:
+            if self.exp[b]:
                 B('  if (CITW_LANE0) {')
                 for n in self.exp[b]:
                     if n not in self.stage0[b]:
                         B('    g_x[%d] = %s;' % (self.xslot[n], ('%s ? 1.0 : 0.0' % self.ref(n)) if g.ty[n] == 'b' else self.ref(n)))
-                for i in pre_x:
-                    B('    g_f[0][stage][%d] = %s;' % (i, self.ref(self.xdot[i])))
                 B('  }')
+            # (derivatives that need no look-up are ready here, but they are STORED behind B1: g_f[0][0] of this env step is row 0 of
+            # the stage derivatives the slowest wavefront may still be combining for the previous step's last stage -- nothing but
+            # timing kept a store in front of B1 behind that read; found by the jitter build, profiles/r04_experiments.md)
             ns0 = n_search(self.rounds[0])
             R0 = self.rounds[0]
 
@@ -1157,9 +1158,9 @@ class TeamGen(codegen.Gen):
                 for n in self.post_sinks[b]:
                     emit_node(n)
             post_x = [i for i, n in enumerate(self.xdot) if self.xdot_owner[i] == b and n in self.post]
-            if post_x:
+            if post_x or pre_x:
                 B('  if (CITW_LANE0) {')
-                for i in post_x:
+                for i in pre_x + post_x:
                     B('    g_f[0][stage][%d] = %s;' % (i, self.ref(self.xdot[i])))
                 B('  }')
             dws = [k for k, o in sorted(self.dw_owner.items()) if o == b]
