@@ -131,7 +131,22 @@ def main():
     ap.add_argument('--lanes', type=int, default=0, help='episodes per wavefront (0 = auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-partition-check', action='store_true')
+    ap.add_argument('--dry-partition', action='store_true', help='print the member / episode blocks of every rank for --gpus N [--total-pop M | --pop P] and exit: no GPU, no launcher')
     a = ap.parse_args()
+    if a.dry_partition:
+        from serl_amd import distributed as sd_
+        wl_, ne_ = WORKLOADS[a.workload], a.num_evals
+        blocks = []
+        for r in range(a.gpus):
+            lo_, hi_ = sd_.member_block(a.total_pop, a.gpus, r) if a.total_pop > 0 else (r * (a.pop or wl_['pop']), (r + 1) * (a.pop or wl_['pop']))
+            blocks.append({'rank': r, 'members': [lo_, hi_], 'n_members': hi_ - lo_, 'episodes': [lo_ * ne_, hi_ * ne_],
+                           'fault_modes_of_first_episodes': [MIXED_MODES[e % 6] for e in range(lo_ * ne_, min(lo_ * ne_ + 6, hi_ * ne_))] if a.workload == 'mixed' else None})
+        total = a.total_pop if a.total_pop > 0 else a.gpus * (a.pop or wl_['pop'])
+        covered = sorted(m for b in blocks for m in range(*b['members']))
+        print(json.dumps({'dry_partition': True, 'n_gpus': a.gpus, 'scaling': 'strong' if a.total_pop > 0 else 'weak', 'total_pop': total,
+                          'num_evals': ne_, 'blocks': blocks, 'covers_every_member_once': covered == list(range(total)),
+                          'gather': 'one all_gather of [num_evals, ceil(pop / world), 6] f64 rows per evaluation (serl_amd/distributed.py gather_rows)'}))
+        return
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(a)
 
@@ -214,6 +229,19 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     steps_local = int(ls.abs().sum())
+    # what the collective layer saw, gathered THROUGH it: every rank's id, its device, its mean kernel time and env steps -- a line from
+    # an N-GPU run proves by itself that N distinct ranks on N distinct devices took part
+    rccl = None
+    if grouped:
+        mine = torch.tensor([float(rank), float(local), float(np.mean(kernel_ms)), float(steps_local), float(torch.cuda.current_device())],
+                            dtype=torch.float64, device=dev)
+        seen = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        seen = torch.stack(seen).cpu().numpy()
+        rccl = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(), 'ranks_seen': [int(v) for v in seen[:, 0]],
+                'local_ranks': [int(v) for v in seen[:, 1]], 'devices': [int(v) for v in seen[:, 4]],
+                'kernel_ms_per_rank': [round(float(v), 3) for v in seen[:, 2]], 'env_steps_per_rank': [int(v) for v in seen[:, 3]],
+                'nccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, 'nccl') else None}
     tt = torch.tensor([dt, float(steps_local)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -261,14 +289,20 @@ def main():
         # the floors are properties of the model DAG (tools/dag/critical_path.py, committed with the generated kernels); the
         # fraction printed is floor / THIS run's measured time per env step
         fl = json.load(open(os.path.join(ROOT, 'profiles', 'floors_current.json')))
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        one_per_team = not mixed and E <= cus          # the fraction is defined for one episode per team (episodes <= CUs of THIS device)
         issue = {'bound': 'valu issue slots (wave-uniform f64 glue: 63 of 64 lanes of every instruction carry the same scalar)',
-                 'issue_floor_us_per_env_step': fl['issue_floor_us_per_env_step'],
+                 'issue_floor_us_per_env_step': fl['issue_floor_trimmed_us_per_env_step'],
+                 'issue_floor_full_dag_us_per_env_step': fl['issue_floor_us_per_env_step'],
                  'dependency_floor_us_per_env_step': fl['dependency_floor_us_per_env_step'],
                  'measured_us_per_env_step': t_step_us,
-                 'issue_floor_frac': fl['issue_floor_us_per_env_step'] / t_step_us if (not mixed and E <= 256) else None,
-                 'frac_note': 'issue floor (minimal instruction count of the model DAG x 4 cycles over the 4 SIMDs of a CU, '
-                              'tools/dag/critical_path.py) / measured time per env step of one team; defined for one episode per '
-                              'team (episodes <= CUs)'}
+                 'issue_floor_frac': fl['issue_floor_trimmed_us_per_env_step'] / t_step_us if one_per_team else None,
+                 'issue_floor_frac_full_dag': fl['issue_floor_us_per_env_step'] / t_step_us if one_per_team else None,
+                 'frac_note': 'issue floor (minimal instruction count of the model DAG x 4 cycles over the 4 SIMDs of a CU, tools/dag/critical_path.py: '
+                              'divisions by proved literals at 4 instructions) / measured time per env step of one team; `issue_floor_frac` is taken against the floor of '
+                              'what the TRIMMED flight condition executes (gated Switch operands and the guarded exp / log10 bodies left out: %d of %d glue instructions), '
+                              '`..._full_dag` against every node of the DAG; defined for one episode per team (episodes <= CUs)'
+                              % (fl['glue_instructions_min_trimmed'], fl['glue_instructions_min'])}
         pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_current.json')))
         if pm.get('workload') == a.workload and pm.get('pop') == pop and ne == 3 and a.lanes == 0 and not strong:
             traffic = pm.get('traffic_bytes_per_launch')
@@ -300,7 +334,10 @@ def main():
                           'frac': ach_f64 / FP64_PEAK},
         'roofline_issue': issue,
         't_step_us': t_step_us,
-        'value_host_buffers': value_host,      # this rank, inputs crossing PCIe per evaluation (informational)
+        # SURVEY 8(d) words the metric "incl. H2D of weights / refs"; the bench contract of this build forbids a PCIe-inclusive rate as
+        # `value`, so it rides along: this rank's evaluation with weights and reference tables crossing PCIe inside the timed region
+        'value_incl_h2d_of_inputs': value_host,
+        'rccl': rccl,
     }
     res.update(res_extra)
     if not a.no_cpu_baseline and world == 1:          # (the contract: the CPU baseline leg runs on rank 0 at N = 1 only)

@@ -16,9 +16,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "citation_libm.h"
 
 #define CIT_MAX_NB 648
-#define CIT_SINCOS(x, s, c_) sincos((x), (s), (c_))
+#define CIT_SINCOS(x, s, c_) citw_sincos((x), (s), (c_))
 #include "citation_leaves.h"
 
 // Read-only model tables (.rodata words [RO_LO_W, RO_HI_W) of the build: aero tables rtConstP, rtConstB,
@@ -101,13 +102,13 @@ __shared__ double g_B[SERL_LDS_B_SLOTS * CIT_MAX_NB];
 #define LIFT_L1D(fn, x, n, u, y) \
   cit_lookup1d_at(&RO_D(x), cit_lookup_index_cached(&RO_D(x), (n), (u), &ixu_##x, &ixi_##x), (u), &RO_D(y))
 #define LIFT_SQRT(x) sqrt(x)
-#define LIFT_POW(x, y) pow(x, y)
+#define LIFT_POW(x, y) citw_pow(x, y)
 #define LIFT_EXP(x) exp(x)
 #define LIFT_LOG10(x) log10(x)
 #define LIFT_LOG(x) log(x)
-#define LIFT_SIN(x) sin(x)
-#define LIFT_COS(x) cos(x)
-#define LIFT_TAN(x) tan(x)
+#define LIFT_SIN(x) citw_sin(x)
+#define LIFT_COS(x) citw_cos(x)
+#define LIFT_TAN(x) citw_tan(x)
 #define LIFT_ATAN(x) atan(x)
 #define LIFT_ATAN2(x, y) atan2(x, y)
 #define LIFT_ASIN(x) asin(x)
@@ -115,7 +116,7 @@ __shared__ double g_B[SERL_LDS_B_SLOTS * CIT_MAX_NB];
 #define LIFT_FLOOR(x) floor(x)
 #define LIFT_ISNAN(x) ((x) != (x))
 #define LIFT_ISINF(x) (((x) == RTINF_D(0)) || ((x) == RTMINF_D(0)))
-#define LIFT_SINCOS(x, s, c_) sincos((x), (s), (c_))
+#define LIFT_SINCOS(x, s, c_) citw_sincos((x), (s), (c_))
 
 // ---- table3 S-function: 3-D table, linear interpolation (mdlOutputs @0x10da0) --------------------
 // The reference walks linearly from the interval cached in IWORK/RWORK; the interval it ends on is

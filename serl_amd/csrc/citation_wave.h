@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "citation_libm.h"
 
 #define CITW_MAX_ROUNDS 3
 

@@ -92,12 +92,22 @@ static int serl_use_teamg(const serl_ctx *c, const serl_rollout_desc *d, int hin
 
 // Beyond 4 x CUs episodes the team kernels still win when the launch has the GPU to itself: 4 x CUs episodes per 30.8 us
 // is the rate of the two-episodes-per-wavefront kernel (8 x CUs per 62.9 us) at half the granularity, and the remainder runs
-// at the rate of its own size class.  Side-by-side launches (concurrent_episodes > 0) keep the half kernel: a team needs a
-// whole CU.  H = 32 only; any kernel_hint other than AUTO switches it off.
+// at the rate of its own size class.  Side-by-side launches (concurrent_episodes > 0) split the CUs by episode share (below; a
+// team needs a whole CU).  H = 32 only; any kernel_hint other than AUTO switches it off.
 static bool serl_use_team_rounds(const serl_ctx *c, const serl_rollout_desc *d, int hint, int episodes)
 {
   if (d->hidden != 32 || hint != SERL_KERNEL_AUTO) return false;
-  return d->concurrent_episodes <= 0 && episodes > 4 * c->num_cus;
+  return episodes > 4 * c->num_cus;
+}
+
+// Work-queue counter of ONE launch: a ring of counters, so that queue launches in flight on different streams (a mixed-fault sweep;
+// validation beside training) never share one -- a second launch's memset or atomicAdd on a shared counter would make the first
+// skip or repeat episodes.  (64 launches later a counter is reused: far beyond what a context keeps in flight.)
+static int32_t *serl_next_queue_counter(serl_ctx *c)
+{
+  int32_t *p = c->queue + c->queue_next;
+  c->queue_next = (c->queue_next + 1) % SERL_QUEUE_COUNTERS;
+  return p;
 }
 
 // The one-wavefront-per-episode kernel runs up to 4 x CUs episodes at once (one per SIMD); beyond that the launch needs a
@@ -292,7 +302,7 @@ int serl_ctx_create(int device, serl_ctx **out)
   }
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
-  HIP_TRY(hipMalloc((void **)&c->queue, SERL_MAX_SLOTS * sizeof(int32_t)));
+  HIP_TRY(hipMalloc((void **)&c->queue, SERL_QUEUE_COUNTERS * sizeof(int32_t)));
   *out = c;
   return SERL_OK;
 }
@@ -428,7 +438,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     int grid = (d->n_episodes + teamg - 1) / teamg;
     if (grid > c->num_cus && d->concurrent_episodes <= 0) {
       grid = c->num_cus;
-      a.queue = c->queue + d->build_slot;
+      a.queue = serl_next_queue_counter(c);
       a.q0 = grid * teamg;
       HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(int32_t), stream));
     } else {
@@ -452,10 +462,24 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     a.block = 512;
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
     a.e0 = 0; a.e_end = d->n_episodes;
-    a.queue = c->queue + d->build_slot;
-    a.q0 = 4 * c->num_cus;
-    HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(int32_t), stream));
-    serl_launch_rollout_teamg(s.code, 4, a, c->num_cus, stream);
+    // alone on the GPU: a team on every CU.  Beside other launches (a mixed-fault sweep: one launch per dynamics build on streams of
+    // their own, each told the episodes of the others) the CUs are split by episode share, so that the teams of all launches are
+    // resident together and every launch drains its own queue at the four-per-team rate (round 3 fell back to two episodes per
+    // WAVEFRONT here: 24.1 M env-steps/s where the queue kernel gives 33.6 M on the nominal workload)
+    int grid = c->num_cus;
+    if (d->concurrent_episodes > 0) {
+      grid = (int)((long long)c->num_cus * d->n_episodes / together);
+      grid = grid < 1 ? 1 : grid;
+    }
+    if (grid * 4 >= d->n_episodes) {          // (a small share of a large sweep: every episode has a lane group, no queue)
+      grid = (d->n_episodes + 3) / 4;
+      a.queue = nullptr; a.q0 = d->n_episodes;
+    } else {
+      a.queue = serl_next_queue_counter(c);
+      a.q0 = 4 * grid;
+      HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(int32_t), stream));
+    }
+    serl_launch_rollout_teamg(s.code, 4, a, grid, stream);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = timed;

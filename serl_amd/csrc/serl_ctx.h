@@ -6,6 +6,7 @@
 #include "../../include/serl_amd.h"
 
 #define SERL_MAX_SLOTS 16
+#define SERL_QUEUE_COUNTERS 64
 
 int serl_fail(int code, const std::string &msg);      // records the thread-local message of serl_last_error()
 #define HIP_TRY(expr)                                                                           \
@@ -36,5 +37,6 @@ struct serl_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
   unsigned long long *prof = nullptr;   // device [32], allocated when SERL_PROFILE=1
-  int32_t *queue = nullptr;             // device [SERL_MAX_SLOTS]: work-queue counters of the multi-episode team kernels, one per build slot
+  int32_t *queue = nullptr;             // device [SERL_QUEUE_COUNTERS]: work-queue counters of the multi-episode team kernels, one per LAUNCH (a ring)
+  int queue_next = 0;
 };

@@ -30,17 +30,26 @@ def calc_smoothness(actions, lengths=None, dt=0.01):
                     out[full.to(actions.device)] = calc_smoothness(actions.index_select(0, full.to(actions.device)), None, dt)
                 return out
     out = torch.empty(E, dtype=torch.float64, device=actions.device)
-    for N in torch.unique(lengths).tolist():      # one batched FFT per distinct episode length
-        idx = torch.nonzero(lengths == N).flatten().to(actions.device)
+    uniq = torch.unique(lengths).tolist()
+    for N in uniq:      # one batched FFT per distinct episode length
+        if len(uniq) == 1 and N == T:
+            idx, y = None, actions                 # every episode ran the whole table (an evaluation's usual case): no gather, no copy
+        else:
+            idx = torch.nonzero(lengths == N).flatten().to(actions.device)
+            y = actions.index_select(0, idx)[:, :N, :]
         if N < 4:
-            out[idx] = 0.0
+            out[idx if idx is not None else slice(None)] = 0.0
             continue
-        y = actions.index_select(0, idx)[:, :N, :]
-        Y = torch.fft.fft(y, n=N, dim=1)[:, 1:N // 2, :]
-        Syy = (Y * Y.conj()).abs() * dt
+        # the signal is real: the half spectrum (rfft) holds every bin 1 .. N/2 - 1 the metric sums -- half the transform and half
+        # the memory of fft (1 536 episodes x 8 001 steps: 0.3 GB of spectrum instead of 0.6); |Y|^2 from the parts, no complex product
+        Y = torch.fft.rfft(y, n=N, dim=1)[:, 1:N // 2, :]
+        Syy = (Y.real.square() + Y.imag.square()) * dt
         freq = torch.linspace(dt, 1 / (2 * dt), N // 2 - 1, dtype=torch.float64, device=actions.device)
         rough = torch.einsum('eij,i->ej', Syy, freq) * 2 / N
-        out[idx] = -(torch.sqrt(rough.sum(-1)) * 100 * (80 / (N * dt)))
+        res = -(torch.sqrt(rough.sum(-1)) * 100 * (80 / (N * dt)))
+        if idx is None:
+            return res
+        out[idx] = res
     return out
 
 

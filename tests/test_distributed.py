@@ -29,7 +29,7 @@ def _local_eval(lo, hi):
 def _stored(lo, hi):
     """stand-in for the rows the rollout kernel stages for members lo..hi-1: deterministic per member"""
     rs = [np.random.RandomState(100 + m) for m in range(lo, hi)]
-    steps = np.array([40 + 7 * m for m in range(lo, hi)], dtype=np.int64)
+    steps = np.array([40 + 7 * (m % 7) for m in range(lo, hi)], dtype=np.int64)
     st = np.zeros((hi - lo, 90, 20), np.float32)
     for j, r in enumerate(rs):
         st[j, :steps[j]] = r.randn(steps[j], 20).astype(np.float32)
@@ -84,6 +84,91 @@ def test_two_rank_gather_equals_single_process():
     for m in range(POP):          # (CPU rings: plain torch indexing; on the GPU replay.store_episodes does this in one launch)
         rings[m].append_rows(torch.from_numpy(got[0]['stored'][0][m, :steps[m]]))
         assert len(rings[m]) == min(64, steps[m]) and rings[m].position == steps[m] % 64
+
+
+def _fake_eval(pop, ne):
+    """deterministic rows per (member, eval) without flying anything: the collective logic is what is under test"""
+    def ev(lo, hi):
+        m = np.arange(lo, hi, dtype=np.float64)[None, :]
+        k = np.arange(ne, dtype=np.float64)[:, None]
+        fit = -np.abs(np.sin(0.37 * m + 1.3 * k)) * 100.0 - 0.01 * m
+        return dict(fitness=fit, returns=fit + 0.5, smoothness=np.cos(m + k), length_t=20.0 - 0.001 * m + 0 * k,
+                    length_steps=(2001 - (m.astype(np.int64) % 17) + 0 * k).astype(np.int32), cost_steps=((m + k) % 5).astype(np.int32))
+    return ev
+
+
+def _worker_many(rank, world, port, q, pop, ne):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from serl_amd import distributed as sd
+    try:
+        res = sd.evaluate_pop_sharded(_fake_eval(pop, ne), pop, ne)
+        lo, hi = sd.member_block(pop, world, rank)
+        st, steps, cost = _stored(lo, hi)
+        gs, gsteps, gcost = sd.gather_stored_episodes(torch.from_numpy(st), steps, cost, pop, world, rank)
+        import hashlib
+        res['stored_digest'] = (hashlib.sha256(gs.numpy().tobytes()).hexdigest(), gsteps.copy(), gcost.copy())
+    except Exception:          # (a rank that dies leaves the others in a collective: tell the test at once)
+        import traceback
+        q.put((rank, {'error': traceback.format_exc()}))
+        os._exit(3)
+    q.put((rank, {k: (v if not isinstance(v, np.ndarray) else v.copy()) for k, v in res.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('pop', [50, 512])
+def test_eight_rank_gather_equals_single_process(pop):
+    """The shape of the node the metric is quoted on: EIGHT ranks (gloo here, RCCL on the GPUs), BASELINE config 3's population
+    of 50 (50 does not divide 8: seven blocks of 7 and one of 1) and config 4's 512 (blocks of 64): result rows, champion / worst
+    and the stored episodes of all members come out on every rank exactly as in one process (base/core/agent.py:234-256)."""
+    sys.path.insert(0, ROOT)
+    from serl_amd import distributed as sd
+    import hashlib
+    ne, world = 3, 8
+    single = sd.evaluate_pop_sharded(_fake_eval(pop, ne), pop, ne)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 30500 + (os.getpid() + pop) % 2000
+    procs = [ctx.Process(target=_worker_many, args=(r, world, port, q, pop, ne)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r_, d_ = q.get(timeout=600)
+        if 'error' in d_:
+            for p in procs:
+                p.kill()
+            pytest.fail('rank %d: %s' % (r_, d_['error']))
+        got[r_] = d_
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    per = (pop + world - 1) // world
+    assert [got[r]['block'] for r in range(world)] == [(min(r * per, pop), min((r + 1) * per, pop)) for r in range(world)]
+    st, steps, cost = _stored(0, pop)
+    want = hashlib.sha256(st.tobytes()).hexdigest()
+    for r in range(world):
+        for k in ('fitness', 'returns', 'smoothness', 'length_t', 'length_steps', 'cost_steps', 'pop_fitness'):
+            np.testing.assert_array_equal(got[r][k], single[k], err_msg='rank %d %s' % (r, k))
+        assert got[r]['champion'] == single['champion'] and got[r]['worst'] == single['worst']
+        dg, gsteps, gcost = got[r]['stored_digest']
+        assert dg == want
+        np.testing.assert_array_equal(gsteps, steps); np.testing.assert_array_equal(gcost, cost)
+
+
+def test_bench_dry_partition_prints_the_member_blocks():
+    """`bench.py --gpus 8 --total-pop 512 --dry-partition` (no GPU, no launcher): the blocks an 8-GPU run would evaluate"""
+    import subprocess, json
+    for args, want in ((['--total-pop', '512'], [[64 * r, 64 * r + 64] for r in range(8)]),
+                       (['--total-pop', '50'], [[7 * r, min(7 * r + 7, 50)] for r in range(8)]),
+                       (['--workload', 'mixed', '--total-pop', '2048'], [[256 * r, 256 * r + 256] for r in range(8)])):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--dry-partition'] + args, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d['covers_every_member_once'] and [b['members'] for b in d['blocks']] == want and d['scaling'] == 'strong'
 
 
 def test_member_blocks_cover_population():
@@ -161,7 +246,7 @@ class _Buf(list):
         self.append(tuple(np.asarray(x).copy() if hasattr(x, 'shape') else x for x in t))
 
 
-def _gen_setup():
+def _gen_setup(n_pop=5):
     import argparse
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -177,10 +262,10 @@ def _gen_setup():
             self.actor = serl_amd.Actor(args)
             unpack_into(self.actor, torch.from_numpy(row[:3715].copy()))
             self.buffer, self.critical_buffer = _Buf(), _Buf()
-    pop = [Agent(rows[i]) for i in (18, 0, 7, 33, 5)]
+    pop = [Agent(rows[i]) for i in ((18, 0, 7, 33, 5) if n_pop == 5 else [(7 * k + 3) % 50 for k in range(n_pop)])]
     rl = Agent(rows[9])
     from serl_amd import refsignals
-    refs = refsignals.synthetic_reference_tables(5 * 2 + 1, 2, 20, seed=3)
+    refs = refsignals.synthetic_reference_tables(n_pop * 2 + 1, 2, 20, seed=3)
     noise = np.clip(0.2 * np.random.RandomState(5).randn(refs.shape[1], 3), -0.5, 0.5)
     return serl_amd, args, pop, rl, refs, noise, OracleEngine()
 
@@ -193,10 +278,10 @@ def _digest(pop, rl, shared, counters, g):
                 rl_fitness=g.rl_episode.fitness if g.rl_episode is not None else None)
 
 
-def _gen_worker(rank, world, port, q, with_rl=True):
+def _gen_worker(rank, world, port, q, with_rl=True, n_pop=5):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    serl_amd, args, pop, rl, refs, noise, eng = _gen_setup()
+    serl_amd, args, pop, rl, refs, noise, eng = _gen_setup(n_pop)
     if not with_rl:
         rl, refs, noise = None, refs[:-1], None
     from serl_amd.generation import evaluate_generation_sharded
@@ -213,25 +298,26 @@ def _gen_worker(rank, world, port, q, with_rl=True):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('world,with_rl', [(2, True), (4, True), (4, False)])
-def test_generation_sharded_over_ranks_equals_single_process(world, with_rl):
+@pytest.mark.parametrize('world,with_rl,n_pop', [(2, True, 5), (4, True, 5), (4, False, 5), (8, True, 50)])
+def test_generation_sharded_over_ranks_equals_single_process(world, with_rl, n_pop):
     """evaluate_generation_sharded on gloo ranks (population of 5; two ranks: blocks 3 + 2; FOUR ranks: blocks 2 + 2 + 1 + 0 -- a
-    rank with an EMPTY member block, which flies the RL actor's exploration episode only, or nothing at all without an RL actor):
+    rank with an EMPTY member block, which flies the RL actor's exploration episode only, or nothing at all without an RL actor;
+    EIGHT ranks, population of 50 -- BASELINE config 3 on one node: blocks of 7 and a last one of 1):
     the gathered fitness table, the champion, the counters and EVERY buffer (shared, per agent, critical) must come out on every
     rank exactly as evaluate_generation fills them in one process.  (Local evaluation = the CPU oracle behind
     RolloutEngine.rollout's call shape: the sharding, the two all-gathers and the buffer order are what is under test.)"""
-    serl_amd, args, pop, rl, refs, noise, eng = _gen_setup()
+    serl_amd, args, pop, rl, refs, noise, eng = _gen_setup(n_pop)
     if not with_rl:
         rl, refs, noise = None, refs[:-1], None
     shared, counters = _Buf(), {}
     g = serl_amd.evaluate_generation(pop, rl, args=args, t_max=20, refs=refs, rl_noise=noise, engine=eng, replay_buffer=shared, counters=counters)
     single = _digest(pop, rl, shared, counters, g)
-    n_agents = 6 if with_rl else 5
+    n_agents = n_pop + (1 if with_rl else 0)
     assert single['lens'][0] == sum(single['lens'][1:1 + n_agents]) and single['counters']['num_episodes'] == n_agents
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = 31500 + (os.getpid() + 7 * world + int(with_rl)) % 2000
-    procs = [ctx.Process(target=_gen_worker, args=(r, world, port, q, with_rl)) for r in range(world)]
+    procs = [ctx.Process(target=_gen_worker, args=(r, world, port, q, with_rl, n_pop)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}

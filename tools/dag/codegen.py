@@ -34,7 +34,12 @@ GATE_LEAF = ('cf', 'ci', 'in', 'in_i', 'true', 'false')
 
 
 
+TRUNC_LITERALS = int(os.environ.get('CITW_TRUNC_LITERALS', 0))      # TIMING EXPERIMENT ONLY (wrong results): f64 literals cut to their high dword (one 32-bit literal operand, no s_mov_b32 pair): what would literals that cost nothing buy?
+
+
 def hexf(bits):
+    if TRUNC_LITERALS:
+        bits &= ~0xffffffff
     x = symex.b2f(bits)
     if x != x:
         return '__longlong_as_double(0x%016xLL)' % bits
@@ -398,7 +403,7 @@ class Gen:
         return '  const double v%d = g_inv[wv][%d];' % (n, k)
 
     BIN = dict(add='+', sub='-', mul='*', div='/', gt='>', ge='>=', lt='<', le='<=', eq='==', ne='!=')
-    FN1 = dict(sqrt='sqrt', exp='exp', log10='log10', log='log', sin='sin', cos='cos', tan='tan', atan='atan', asin='asin',
+    FN1 = dict(sqrt='sqrt', exp='exp', log10='log10', log='log', sin='citw_sin', cos='citw_cos', tan='citw_tan', atan='atan', asin='asin',
                acos='acos', floor='floor', fabs='fabs')
 
     _cdiv = {}
@@ -431,7 +436,7 @@ class Gen:
         elif op in self.FN1:
             e = '%s(%s)' % (self.FN1[op], R(t[1]))
         elif op in ('pow', 'atan2'):
-            e = '%s(%s, %s)' % (op, R(t[1]), R(t[2]))
+            e = '%s(%s, %s)' % ({'pow': 'citw_pow'}.get(op, op), R(t[1]), R(t[2]))
         elif op == 'powsnf':
             e = 'citw_powd_snf(%s, %s)' % (R(t[1]), R(t[2]))
         elif op == 'sel':
@@ -496,7 +501,7 @@ class Gen:
                     assert self.inv[m], 'non-invariant node %s in the invariants function' % (t[:2],)
                     if t[0] in ('sc_sin', 'sc_cos'):
                         s_, c_ = g.memo.get(('sc_sin', t[1])), g.memo.get(('sc_cos', t[1]))
-                        P('  double v%d = 0.0, v%d = 0.0; sincos(%s, &v%d, &v%d); (void)v%d; (void)v%d;' % (s_, c_, self.ref(t[1]), s_, c_, s_, c_))
+                        P('  double v%d = 0.0, v%d = 0.0; citw_sincos(%s, &v%d, &v%d); (void)v%d; (void)v%d;' % (s_, c_, self.ref(t[1]), s_, c_, s_, c_))
                         emitted.add(s_); emitted.add(c_)
                         continue
                     s = self.stmt(m)
@@ -666,7 +671,7 @@ class Gen:
                         assert self.outslot[m][0] in done_rounds, 'look-up result used before its round'
                     if t[0] in ('sc_sin', 'sc_cos'):
                         s_, c_ = g.memo.get(('sc_sin', t[1])), g.memo.get(('sc_cos', t[1]))
-                        P('  double v%d, v%d; sincos(%s, &v%d, &v%d);' % (s_, c_, self.ref(t[1]), s_, c_))
+                        P('  double v%d, v%d; citw_sincos(%s, &v%d, &v%d);' % (s_, c_, self.ref(t[1]), s_, c_))
                         emitted.add(s_); emitted.add(c_)
                         continue
                     s = self.stmt(m)
@@ -704,7 +709,7 @@ class Gen:
                 cond = '(lane >= %d && lane < %d)' % (j, k) if k - j > 1 else '(lane == %d)' % j
                 if k - j == 1 and j in self.call_guard:
                     cond = '(lane == %d && %s%s)' % (j, '' if self.call_guard[j][1] else '!', self.ref(self.call_guard[j][0]))
-                call = {'sincos': 'sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = pow(a_, %s)' % hexf(prm)}.get(fn, 'r0_ = %s(a_)' % fn)
+                call = {'sincos': 'citw_sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = citw_pow(a_, %s)' % hexf(prm), 'tan': 'r0_ = citw_tan(a_)'}.get(fn, 'r0_ = %s(a_)' % fn)
                 P('    %sif %s { %s; }' % ('' if first else 'else ', cond, call))
                 first = False
                 j = k

@@ -694,7 +694,7 @@ class TeamGen(codegen.Gen):
                             assert self.outslot[m][0] in done_rounds, 'look-up result used before its round'
                         if t[0] in ('sc_sin', 'sc_cos') and m not in self.libm_slot:
                             s_, c_ = g.memo.get(('sc_sin', t[1])), g.memo.get(('sc_cos', t[1]))
-                            B('  double v%d, v%d; sincos(%s, &v%d, &v%d);' % (s_, c_, self.ref(t[1]), s_, c_))
+                            B('  double v%d, v%d; citw_sincos(%s, &v%d, &v%d);' % (s_, c_, self.ref(t[1]), s_, c_))
                             emitted.add(s_); emitted.add(c_)
                             continue
                         s = self.stmt(m)
@@ -737,7 +737,7 @@ class TeamGen(codegen.Gen):
                     B('    const int j_ = %s-1;' % ''.join('lane == %d ? %d : ' % (g.nodes[k_[1]][2], i_) for i_, k_ in enumerate(keys)))
                     B('    double r0_ = 0.0, r1_ = 0.0;')
                     B('    if (j_ >= 0) {')
-                    B('      %s;' % ('sincos(XL, &r0_, &r1_)' if fn == 'sincos' else 'r0_ = %s(XL)' % fn))
+                    B('      %s;' % ('citw_sincos(XL, &r0_, &r1_)' if fn == 'sincos' else 'r0_ = %s(XL)' % {'tan': 'citw_tan'}.get(fn, fn)))
                     B('      g_m[%d][2 * (%d + j_)] = r0_; g_m[%d][2 * (%d + j_) + 1] = r1_;' % (b, lo, b, lo))
                     B('    }')
                     B('  }')
@@ -761,7 +761,7 @@ class TeamGen(codegen.Gen):
                     if k - i == 1 and calls[i] in self.call_guard:
                         gd = self.call_guard[calls[i]]
                         cond = '(l_ == %d && %s%s)' % (i, '' if gd[1] else '!', self.ref(gd[0]))
-                    call = {'sincos': 'sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = pow(a_, %s)' % hexf(prm)}.get(fn, 'r0_ = %s(a_)' % fn)
+                    call = {'sincos': 'citw_sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = citw_pow(a_, %s)' % hexf(prm), 'tan': 'r0_ = citw_tan(a_)'}.get(fn, 'r0_ = %s(a_)' % fn)
                     early = any(self.flag_of.get(nd, b) == 8 + b for nd in self.libm_calls[calls[i]][1].values())
                     if early and first:
                         # the first function's results leave at once, behind a flag of their own
@@ -812,7 +812,7 @@ class TeamGen(codegen.Gen):
                     while k < len(lst) and lst[k][0][0] == fn and (fn != 'pow' or lst[k][0][2] == prm):
                         k += 1
                     cond = '(lane >= %d && lane < %d)' % (j, k) if k - j > 1 else '(lane == %d)' % j
-                    call = {'sincos': 'sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = pow(a_, %s)' % hexf(prm)}.get(fn, 'r0_ = %s(a_)' % fn)
+                    call = {'sincos': 'citw_sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = citw_pow(a_, %s)' % hexf(prm), 'tan': 'r0_ = citw_tan(a_)'}.get(fn, 'r0_ = %s(a_)' % fn)
                     B('    %sif %s { %s; }' % ('' if first else 'else ', cond, call))
                     first = False
                     j = k
