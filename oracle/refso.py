@@ -29,13 +29,19 @@ def available():
     return reference_root() is not None
 
 
+_extracted = {}          # build -> path of its library extracted from the staged archive (once per process, removed at exit)
+
+
 def so_path(build):
     rel = 'envs/%s/_citation.cpython-38-x86_64-linux-gnu.so' % build
     if os.path.isfile(REF):          # staged archive: shared objects cannot be loaded from inside a zip
-        import zipfile
-        d = tempfile.mkdtemp(prefix='refso_zip_')
-        with zipfile.ZipFile(REF) as z:
-            return z.extract(rel, d)
+        if build not in _extracted:
+            import atexit, zipfile
+            d = tempfile.mkdtemp(prefix='refso_zip_')
+            atexit.register(shutil.rmtree, d, True)
+            with zipfile.ZipFile(REF) as z:
+                _extracted[build] = z.extract(rel, d)
+        return _extracted[build]
     return os.path.join(REF, rel)
 
 

@@ -17,7 +17,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fP
 def _deps():
     out = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(('.hip', '.inc'))]
     out += [os.path.join(ROOT, 'oracle', 'gen', 'citation_%s.inc' % v) for v in ('nominal', 'ice')]
-    out += [os.path.join(ROOT, 'serl_amd', 'csrc', f) for f in ('citation_dev.h', 'citation_leaves.h', 'citation_step_dev.h',
+    out += [os.path.join(ROOT, 'serl_amd', 'csrc', f) for f in ('citation_dev.h', 'citation_leaves.h', 'citation_step_dev.h', 'citation_libm.h',
                                                                 'rollout_device.h', 'rollout_variant.inc')]
     out.append(os.path.join(ROOT, 'include', 'serl_amd.h'))
     return out
@@ -59,8 +59,32 @@ def lib():
         L.serl_xcheck_rollout.argtypes = [ctypes.c_int, VP, ctypes.c_int, ctypes.c_double, VP, ctypes.c_int, VP]
         L.serl_xcheck_dyn_open_loop.argtypes = [ctypes.c_int, VP, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, VP, VP,
                                                ctypes.c_int, VP]
+        L.serl_xcheck_div_const.argtypes = [VP, ctypes.c_int, ctypes.c_double, ctypes.c_double, VP, VP, VP]
+        L.serl_xcheck_libm.argtypes = [ctypes.c_int, VP, ctypes.c_int, ctypes.c_double, VP, VP, VP]
         _lib = L
     return _lib
+
+
+def div_const(x, c, rc):
+    """(x / c by the product's reciprocal + fma correction, x / c by the IEEE division) on the GPU, as numpy arrays"""
+    import torch
+    xt = torch.as_tensor(x, dtype=torch.float64).cuda().contiguous()
+    fast, ieee = torch.empty_like(xt), torch.empty_like(xt)
+    rc_ = lib().serl_xcheck_div_const(xt.data_ptr(), xt.numel(), float(c), float(rc), fast.data_ptr(), ieee.data_ptr(), None)
+    assert rc_ == 0
+    torch.cuda.synchronize()
+    return fast.cpu().numpy(), ieee.cpu().numpy()
+
+
+def libm(kind, x, c=0.0):
+    """citw_sincos (kind 0) / citw_tan (1) / citw_pow(x, c) (2) of serl_amd/csrc/citation_libm.h on the GPU"""
+    import torch
+    xt = torch.as_tensor(x, dtype=torch.float64).cuda().contiguous()
+    o0, o1 = torch.empty_like(xt), torch.empty_like(xt)
+    rc_ = lib().serl_xcheck_libm(int(kind), xt.data_ptr(), xt.numel(), float(c), o0.data_ptr(), o1.data_ptr(), None)
+    assert rc_ == 0
+    torch.cuda.synchronize()
+    return o0.cpu().numpy(), o1.cpu().numpy()
 
 
 def rollout(weights, spec, member_of_episode, ref, *, build='h2000_v90', t_max=80.0, lanes_per_wave=8):

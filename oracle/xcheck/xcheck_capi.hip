@@ -15,6 +15,30 @@ void serl_xcheck_launch_dyn_ice(const RolloutArgs &a, const double *cmds, double
 
 static thread_local std::string g_xerr;
 
+// ---- unit checks of product device functions (tests/test_gpu_rollout.py): arrays in, arrays out ----------------------------------
+#include "citation_libm.h"
+// x / c by the reciprocal + fma correction of the product (citation_wave.h: citw_div_const; restated here with the same four
+// operations -- the header itself declares the kernels' LDS) and by the IEEE division
+__global__ void xcheck_div_const_kernel(const double *x, int n, double c, double rc, double *fast, double *ieee)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double q = x[i] * rc;
+  const double r = __builtin_fma(-q, c, x[i]);
+  const double q2 = __builtin_fma(r, rc, q);
+  fast[i] = __builtin_amdgcn_div_fixup(q2, c, x[i]);
+  ieee[i] = x[i] / c;
+}
+// kind 0: citw_sincos -> (o0, o1); 1: citw_tan -> o0; 2: citw_pow(x, c) -> o0
+__global__ void xcheck_libm_kernel(int kind, const double *x, int n, double c, double *o0, double *o1)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (kind == 0) citw_sincos(x[i], &o0[i], &o1[i]);
+  else if (kind == 1) o0[i] = citw_tan(x[i]);
+  else o0[i] = citw_pow(x[i], c);
+}
+
 static void xcheck_args(RolloutArgs &a, const double *blob, int n_ro, double dt, int lanes, int waves, int *grid)
 {
   a.ro = blob; a.t3 = blob + n_ro; a.x0 = a.t3 + 46; a.dw0 = a.x0 + 19;
@@ -70,6 +94,18 @@ int serl_xcheck_dyn_open_loop(int code, const double *blob, int n_ro, double dt,
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) { g_xerr = std::string("serl_xcheck_dyn_open_loop: ") + hipGetErrorString(e); return SERL_E_HIP; }
   return SERL_OK;
+}
+
+int serl_xcheck_div_const(const double *x, int n, double c, double rc, double *fast, double *ieee, void *stream)
+{
+  hipLaunchKernelGGL(xcheck_div_const_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, n, c, rc, fast, ieee);
+  return hipGetLastError() == hipSuccess ? SERL_OK : SERL_E_HIP;
+}
+
+int serl_xcheck_libm(int kind, const double *x, int n, double c, double *o0, double *o1, void *stream)
+{
+  hipLaunchKernelGGL(xcheck_libm_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, kind, x, n, c, o0, o1);
+  return hipGetLastError() == hipSuccess ? SERL_OK : SERL_E_HIP;
 }
 
 }  // extern "C"

@@ -31,6 +31,9 @@ SERL_DECL_WAVE(nominal) SERL_DECL_WAVE(ice) SERL_DECL_WAVE(cg_timed) SERL_DECL_W
   void serl_launch_rollout_teams_##v(const RolloutArgs &a, int grid, hipStream_t stream);                         \
   void serl_launch_dyn_team_##v(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
 SERL_DECL_TEAM(nominal) SERL_DECL_TEAM(ice) SERL_DECL_TEAM(cg_timed) SERL_DECL_TEAM(gust) SERL_DECL_TEAM(test)
+// ... with one forward pass over two actor wavefronts (rollout_teams2_<v>.hip: hidden > 64)
+#define SERL_DECL_TEAMS2(v) void serl_launch_rollout_teams2_##v(const RolloutArgs &a, int grid, hipStream_t stream);
+SERL_DECL_TEAMS2(nominal) SERL_DECL_TEAMS2(ice) SERL_DECL_TEAMS2(cg_timed) SERL_DECL_TEAMS2(gust) SERL_DECL_TEAMS2(test)
 
 // two episodes per wavefront (rollout_half.inc): beyond one wavefront per SIMD
 #define SERL_DECL_HALF(v) void serl_launch_rollout_half_##v(const RolloutArgs &a, int grid, hipStream_t stream);
@@ -134,6 +137,18 @@ static void serl_launch_rollout_team(int code, const RolloutArgs &a, int grid, h
 {
   // (rollout_device.h: serl_lds_actor_ok) shapes whose weights the actor wavefront streams have a kernel of their own
   const bool lds_actor = a.d.hidden == 32 && a.d.num_layers <= 3 && a.d.state_dim == 7 && a.d.action_dim == 3;
+  if (!lds_actor && a.d.hidden > 64 && a.d.hidden <= 128) {
+    // a lone actor wavefront walks such a layer twice (rows 0..63, then the rest on a few lanes) and needs most of a step for its
+    // forward pass: two actor wavefronts share it beside a six-wavefront team (SERL10: 22.8 -> us per env step, profiles/r04_*)
+    switch (code) {
+      case SERL_DYN_NOMINAL: serl_launch_rollout_teams2_nominal(a, grid, stream); break;
+      case SERL_DYN_ICE: serl_launch_rollout_teams2_ice(a, grid, stream); break;
+      case SERL_DYN_CG_TIMED: serl_launch_rollout_teams2_cg_timed(a, grid, stream); break;
+      case SERL_DYN_GUST: serl_launch_rollout_teams2_gust(a, grid, stream); break;
+      default: serl_launch_rollout_teams2_test(a, grid, stream); break;
+    }
+    return;
+  }
   if (!lds_actor) {
     switch (code) {
       case SERL_DYN_NOMINAL: serl_launch_rollout_teams_nominal(a, grid, stream); break;

@@ -71,13 +71,14 @@ ACTOR_POST = float(os.environ.get('CITW_TEAM_ACTOR_POST', 0))
 COLD_COST = float(os.environ.get('CITW_TEAM_COLD_COST', 1.0))        # balancer: cost factor of gated nodes that the trimmed flight condition does not execute
 LIBM_WAVE = {kv.split(':')[0]: int(kv.split(':')[1]) for kv in os.environ.get('CITW_TEAM_LIBM_WAVE', '').split(',') if ':' in kv}     # libm function -> the helper that makes its calls (default: the least loaded one)
 EARLY_FLAG = int(os.environ.get('CITW_TEAM_EARLY_FLAG', 2))             # 2: the first libm function group of a wavefront (sincos in front of tan) is announced by a flag of its own, g_flag[8 + q] -- except on the wavefront of the handed-over chain (1: there too -- with lane groups that produced NaNs in the first launch of a process, r03 sweeps 39 / 41, cause not found; 0: off)
+TAN_MERGE = int(os.environ.get('CITW_TEAM_TAN_MERGE', 1))               # 1: the tan lanes of a wavefront ride its sincos pass and divide behind it (no second body)
 TWO_PASS = int(os.environ.get('CITW_TEAM_TWO_PASS', 1))                 # 1: a helper computes what needs no foreign libm result before its first flag wait, node by node
 SPEC = int(os.environ.get('CITW_TEAM_SPEC', 1))                        # 1: emit the merged descriptor row + the precomputed look-up lanes of wave 0 (citw_spec_pre / citw_spec_tail; compiled in with -DCITW_SPEC_LOOKUP=1)
 STAGE0 = int(os.environ.get('CITW_TEAM_STAGE0', 1))                    # 1: glue that depends on the command vector alone runs in the first of the six evaluations only (its look-up inputs / exchanged values keep their LDS slots)
 OWN_LOOKUPS = int(os.environ.get('CITW_TEAM_OWN_LOOKUPS', 0))          # 1: the helper that computes a look-up input also searches / interpolates the (1-D) tables keyed on it: wave 0 never waits for it
 SPLIT_IN = int(os.environ.get('CITW_TEAM_SPLIT_INPUTS', 1))           # 1: the heaviest round-1 input cone (pow chain) runs on a helper, handed over by flag
-FN_SCALE = float(os.environ.get('CITW_TEAM_FN_SCALE', 1.0))            # libm bodies relative to the first estimates in FN
-LIBM_SCALE = float(os.environ.get('CITW_TEAM_LIBM_SCALE', 2.5))        # extra factor for the handed-over cone's libm bodies
+FN_SCALE = float(os.environ.get('CITW_TEAM_FN_SCALE', 0.6))            # libm bodies relative to the first estimates in FN (round 4: the short bodies of citation_libm.h -- 1.0: 17.21 us per env step, 0.6 with LIBM_SCALE 1.5: 16.85; 39 random settings around it 16.79 - 18.99, profiles/r04_experiments.md)
+LIBM_SCALE = float(os.environ.get('CITW_TEAM_LIBM_SCALE', 1.5))        # extra factor for the handed-over cone's libm bodies (2.5 with ocml's pow)
 AFFINITY = float(os.environ.get('CITW_TEAM_AFFINITY', 1.0))            # > 0: a sink leans towards the wave that already holds most of its cone
 SPLIT_CHAIN = int(os.environ.get('CITW_TEAM_SPLIT_CHAIN', 0))      # 1: the engine look-up chain (chain round -> second round -> N1 / N2 derivatives) on a wavefront of its own
 ENGINE_WAVE = int(os.environ.get('CITW_TEAM_ENGINE_WAVE', 4))      # ... this one
@@ -752,12 +753,26 @@ class TeamGen(codegen.Gen):
                 B('    const double a_ = g_m[%d][48 + (lane >= %d && lane < %d ? lane : %d)];' % (b, lo, lo + len(calls), lo))
                 B('    double r0_ = 0.0, r1_ = 0.0;')
                 i, first, first_done = 0, True, 0
+                # tan lanes ride the sincos pass (citw_tan IS sin / cos of citw_sincos, citation_libm.h): one body for both, the
+                # tan lanes divide behind it -- same bits as a call of citw_tan, ~65 instructions less on the wavefront every helper waits for
+                fns_ = [self.libm_calls[j][0][0] for j in calls]
+                n_sc = sum(1 for f_ in fns_ if f_ == 'sincos')
+                n_tan = sum(1 for f_ in fns_ if f_ == 'tan')
+                tan_merge = (TAN_MERGE and n_sc > 0 and n_tan > 0 and fns_[:n_sc + n_tan] == ['sincos'] * n_sc + ['tan'] * n_tan
+                             and not any(calls[q] in self.call_guard for q in range(n_sc + n_tan)))
                 while i < len(calls):
                     (fn, arg, prm) = self.libm_calls[calls[i]][0]
                     k = i
                     while k < len(calls) and self.libm_calls[calls[k]][0][0] == fn and (fn != 'pow' or self.libm_calls[calls[k]][0][2] == prm):
                         k += 1
                     cond = '(l_ >= %d && l_ < %d)' % (i, k) if k - i > 1 else '(l_ == %d)' % i
+                    if tan_merge and fn == 'sincos':
+                        cond = '(l_ >= %d && l_ < %d)' % (i, k + n_tan)           # ... the tan lanes too
+                    if tan_merge and fn == 'tan':
+                        B('    if %s { r0_ = r0_ / r1_; r1_ = 0.0; }   /* tan = sin / cos of the pass above */' % cond)
+                        first = True
+                        i = k
+                        continue
                     if k - i == 1 and calls[i] in self.call_guard:
                         gd = self.call_guard[calls[i]]
                         cond = '(l_ == %d && %s%s)' % (i, '' if gd[1] else '!', self.ref(gd[0]))
@@ -949,9 +964,11 @@ class TeamGen(codegen.Gen):
             blk = self.stage0[b]
             if blk:
                 for n in [m for m in self.order if m in blk]:
-                    for c in list(build_dag.children(g, n)) + ([self.gate[n][0]] if n in self.gate else []):
+                    # (what the block reads from outside, a gate's condition included -- if this wavefront has the condition at all: otherwise
+                    # emit_node computes the gated value unconditionally, like everywhere else)
+                    for c in list(build_dag.children(g, n)) + ([self.gate[n][0]] if (n in self.gate and self.gate[n][0] in self.have[b]) else []):
                         if c not in blk and g.nodes[c][0] not in LEAF:
-                            emit_node(c, self.have[b])      # (what the block reads from outside, a gate's condition included)
+                            emit_node(c, self.have[b])
                 B('  if (stage == 0) {   /* ---- what depends on the command vector alone: once per env step; its look-up inputs and exchanged values keep their LDS slots */')
                 for n in [m for m in self.order if m in blk]:
                     emit_node(n, self.have[b])
