@@ -442,7 +442,8 @@ static __device__ void serl_actor_forward_wave(const serl_rollout_desc &dd, cons
 // credit is therefore paid per LAYER, right behind each exchange, with counts both wavefronts compute alike: sync(stage, L + 2).
 template <class Sync>
 static __device__ void serl_actor_forward_split(const serl_rollout_desc &dd, const float *w_generic, const float obs[7], float act_out[3],
-                                                Sync &sync, const int part, float (*hx)[128], unsigned *xflag, const unsigned seq0)
+                                                Sync &sync, const int part, float (*hx)[128], unsigned *xflag, const unsigned seq0,
+                                                unsigned long long *xwait = nullptr /* development aid: cycles spent waiting for the partner */)
 {
   const int H = __builtin_amdgcn_readfirstlane(dd.hidden), L = __builtin_amdgcn_readfirstlane(dd.num_layers);
   const int act = __builtin_amdgcn_readfirstlane(dd.activation);
@@ -469,7 +470,9 @@ static __device__ void serl_actor_forward_split(const serl_rollout_desc &dd, con
     citw_jitter_(0xa50u + (unsigned)part, seq);
 #endif
     __hip_atomic_store(&xflag[part], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long tw0 = xwait ? __builtin_readcyclecounter() : 0ull;
     while ((int)(__hip_atomic_load(&xflag[1 - part], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - seq) < 0) __builtin_amdgcn_s_sleep(1);
+    if (xwait) *xwait += __builtin_readcyclecounter() - tw0;
 #if defined(CITW_JITTER) && CITW_JITTER
     citw_jitter_(0xa60u + (unsigned)part, seq);
 #endif

@@ -133,13 +133,14 @@ static bool serl_use_team(const serl_ctx *c, int hint, int episodes)
   return episodes <= c->num_cus;
 }
 
-static void serl_launch_rollout_team(int code, const RolloutArgs &a, int grid, hipStream_t stream)
+static void serl_launch_rollout_team(int code, const RolloutArgs &a, int grid, hipStream_t stream, bool split_actor = false)
 {
   // (rollout_device.h: serl_lds_actor_ok) shapes whose weights the actor wavefront streams have a kernel of their own
   const bool lds_actor = a.d.hidden == 32 && a.d.num_layers <= 3 && a.d.state_dim == 7 && a.d.action_dim == 3;
-  if (!lds_actor && a.d.hidden > 64 && a.d.hidden <= 128) {
-    // a lone actor wavefront walks such a layer twice (rows 0..63, then the rest on a few lanes) and needs most of a step for its
-    // forward pass: two actor wavefronts share it beside a six-wavefront team (SERL10: 22.8 -> us per env step, profiles/r04_*)
+  if (!lds_actor && split_actor && a.d.hidden > 64 && a.d.hidden <= 128) {
+    // (development override SERL_SPLIT_ACTOR=1) two actor wavefronts share ONE forward pass beside a six-wavefront team: round 4
+    // built it for the shapes whose lone actor wavefront needed a whole step (H = 72: 43 k cycles) -- and then found that a
+    // shape-specialised forward (serl_actor_forward_big: 25 k) on ONE wavefront beside the seven-wavefront team is faster
     switch (code) {
       case SERL_DYN_NOMINAL: serl_launch_rollout_teams2_nominal(a, grid, stream); break;
       case SERL_DYN_ICE: serl_launch_rollout_teams2_ice(a, grid, stream); break;
@@ -312,6 +313,7 @@ int serl_ctx_create(int device, serl_ctx **out)
     }
     c->env_waves_per_block = (e = getenv("SERL_WAVES_PER_BLOCK")) ? atoi(e) : -1;
     c->env_profile = getenv("SERL_PROFILE") != nullptr;
+    c->env_split_actor = (e = getenv("SERL_SPLIT_ACTOR")) ? atoi(e) : 0;
     c->env_jitter = (e = getenv("SERL_JITTER_SEED")) ? (unsigned)strtoul(e, nullptr, 0) : 0u;
     c->env_jitter_sites = (e = getenv("SERL_JITTER_SITES")) ? (unsigned)strtoul(e, nullptr, 0) : ~0u;
   }
@@ -438,7 +440,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     a.lanes = 1;
     a.block = 128;
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
-    serl_launch_rollout_team(s.code, a, d->n_episodes, stream);
+    serl_launch_rollout_team(s.code, a, d->n_episodes, stream, c->env_split_actor != 0);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = timed;

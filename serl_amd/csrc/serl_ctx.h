@@ -31,6 +31,8 @@ struct serl_ctx {
   int lds_per_block = 65536;            // sharedMemPerBlockOptin
   // environment overrides, read once when the context is made (-1 = not set)
   int env_kernel = 0 /* serl_kernel_hint from SERL_KERNEL */, env_waves_per_block = -1, env_profile = 0;
+  int env_split_actor = 0;              // SERL_SPLIT_ACTOR=1: streamed actors of one-episode teams (hidden > 64) on TWO actor wavefronts that share the forward pass
+                                        // (rollout_teams2_<v>.hip; measured slower than one wavefront with the specialised forward: profiles/r04_experiments.md)
   unsigned env_jitter_sites = ~0u;      // SERL_JITTER_SITES: classes of sites that pause (citation_wave.h; all by default)
   unsigned env_jitter = 0;              // SERL_JITTER_SEED: seed of the hand-over stress builds' pauses (libserl_amd_jitter.so; the product ignores it)
   BuildSlot slots[SERL_MAX_SLOTS];

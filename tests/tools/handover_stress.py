@@ -36,6 +36,7 @@ def cases(cus):
     return {
         'team': ('serl50', 'team', 12),                # seven team wavefronts + the actor wavefront, weights in LDS
         'teams': ('serl10', 'team', 6),                # ... the actor streams its weights
+        'teams_split': ('serl10', 'team', 6),          # ... on TWO actor wavefronts that share the forward pass (SERL_SPLIT_ACTOR=1, rollout_teams2_<v>.hip)
         'team2': ('serl50', 'team2', 21),              # two episodes per team (an odd count: one lane group stays empty)
         'team2s': ('serl10', 'team2', 11),             # six team wavefronts + two streaming actor wavefronts
         'team4': ('serl50', 'team4', 35),              # four episodes per team
@@ -63,9 +64,14 @@ def main():
     out = {}
     for seed in seeds:
         os.environ['SERL_JITTER_SEED'] = str(seed)          # read by serl_ctx_create
+        os.environ['SERL_SPLIT_ACTOR'] = '0'
         eng = serl_amd.RolloutEngine(0)
+        os.environ['SERL_SPLIT_ACTOR'] = '1'
+        eng_split = serl_amd.RolloutEngine(0)
+        engines = (eng, eng_split)
         for name, case in cases(cus).items():
             tag, kern, n = case
+            eng = engines[1] if name == 'teams_split' else engines[0]
             w, moe, ref, tick0 = inputs(name, case, build)
             n_ = NET[tag]
             spec = serl_amd.NetSpec(n_['state_dim'], n_['action_dim'], n_['hidden'], n_['num_layers'], n_['activation'])
@@ -75,7 +81,8 @@ def main():
                 out['%s_%d_%s' % (name, seed, key)] = r[key].cpu().numpy()
             print(build, name, 'seed', seed, 'kernel ms %.1f' % eng.last_kernel_ms, 'nan', int(np.isnan(out['%s_%d_fitness' % (name, seed)]).sum()),
                   'payloads', sorted(set('%#x' % v for v in out['%s_%d_fitness' % (name, seed)][np.isnan(out['%s_%d_fitness' % (name, seed)])].view(np.uint64)))[:6], flush=True)
-        eng.close()
+        for e_ in engines:
+            e_.close()
     np.savez(out_path, **out)
 
 

@@ -28,7 +28,8 @@ for E in [int(x) for x in sys.argv[1:]] or [150, 1024]:
         st = max(buf[3], 1)
         res['cyc_E%d' % E] = [int(buf[0] / st), int(buf[1] / st), int(buf[2] / st)]
         res['simd_E%d' % E] = [int(v) - 100 for v in buf[16:25] if v]      # SIMD of every wavefront of workgroup 0
-        res['actor_busy_E%d' % E] = int(buf[31] / st)                      # cycles per env step the actor wavefront spends on a forward pass
+        res['actor_busy_E%d' % E] = int(buf[31] / st)
+        res['split_actor_E%d' % E] = dict(forward=[int(buf[26] / st), int(buf[27] / st)], partner_wait=[int(buf[28] / st), int(buf[29] / st)], obs_wait=[int(buf[30] / st), int(buf[31] / st)])                      # cycles per env step the actor wavefront spends on a forward pass
         if any(buf[4:16]):
             res['phase_E%d' % E] = [int(v / st) for v in buf[4:32]]
     res['fit0_E%d' % E] = float(out['fitness'][0])
