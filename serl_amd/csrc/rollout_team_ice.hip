@@ -7,6 +7,16 @@
 #endif
 #define CITW_OUT2_ROWS 1
 #define CITW_INV_SLOTS 8
+// Which role of the partitioned evaluation runs on which hardware wavefront (w and w + 4 share a SIMD), and a static issue priority
+// (round 4, sweeps k / l after the short libm and the new balance, 150 episodes, us per env step: identity 16.85 - 16.89; roles 1 and 6
+// exchanged -- role 1, last at B1, beside role 2, which waits longest there; role 5 beside role 6 -- 16.60; + role 1 at priority 1:
+// 16.56 - 16.61).  One episode per team only: the lane-group kernels keep the identity.
+#ifndef SERL_TEAM_ROLES
+#define SERL_TEAM_ROLES {0, 6, 2, 3, 4, 5, 1, 7, 8, 9, 10, 11, 12, 13, 14, 15}
+#endif
+#ifndef CITW_ROLE_PRIO_MASK
+#define CITW_ROLE_PRIO_MASK 0x02
+#endif
 #include "citation_wave.h"
 #include "rollout_device.h"
 #include "gen/citation_ice_wave.inc"   // look-up descriptor tables (shared with the one-wave kernels)
