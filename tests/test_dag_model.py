@@ -125,3 +125,85 @@ def test_gated_cones_are_read_only_through_their_selects(variant):
                 t = g.nodes[u]
                 assert t[0] == 'sel' and t[1] == c and t[idx] == m and t[5 - idx] != m, (variant, c, pol, m, u, t[:4])
     assert total >= 100            # (nominal: 188 of 1 086 nodes)
+
+
+@pytest.mark.parametrize('variant,suffix', [('nominal', ''), ('ice', ''), ('cg_timed', ''), ('gust', ''), ('test', ''), ('nominal', '6'), ('gust', '6')])
+def test_every_cross_wavefront_read_of_the_generated_team_code_is_covered_by_its_flag(variant, suffix):
+    """The hand-over protocol of gen/citation_<v>_team.inc, checked on the EMITTED TEXT, independently of the generator's own bookkeeping
+    (a consumer that reads a slot before, or without, its producer's store would return a plausible stale value):
+      * in front of barrier B1 a wavefront may read another wavefront's libm results g_m[CITW_MROW(q)][s] only behind a wait on the flag
+        that the producer raises BEHIND its store of slot s -- g_flag[8 + q] for the results stored in front of its early flag,
+        g_flag[q] (which also covers the early ones) for the rest;
+      * the producer's stores of its result slots precede the matching raise, and a wavefront-scope fence stands between the stores and
+        the wavefront's own loads of them (the lanes that made the calls are not the lanes that read);
+      * behind B1 a value of the task graph g_y[CITW_YOFF + s] is read from another wavefront only through citw_pflag_wait_load on the
+        producer's flag with the publication count the producer raises behind its store of that slot;
+      * every derivative is stored behind B1 (row 0 of g_f is still being combined by a late wavefront in front of it);
+      * behind B1, and only there, results of other wavefronts are read without a wait (the barrier orders them)."""
+    import re
+    text = open(os.path.join(ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_team%s.inc' % (variant, suffix))).read()
+    funcs = re.split(r'(?=static __device__ CITW_EVAL_INLINE double citw_\w+_team_eval_w\d+\()', text)[1:]
+    assert len(funcs) == (6 if suffix == '6' else 7)
+    # ---- producers: which flag covers which slot of g_m, which publication count covers which slot of g_y
+    m_flag, y_pub = {}, {}
+    for f in funcs:
+        b = int(re.match(r'static __device__ CITW_EVAL_INLINE double citw_\w+_team_eval_w(\d+)\(', f).group(1))
+        pre = f.split('CITW_TEAM_BARRIER1()')[0]
+        stored = []
+        for line in pre.splitlines():
+            st = re.search(r'if \(l_ >= (\d+) && l_ < (\d+)\) \{ g_m\[CITW_MROW\((\d+)\)\]\[2 \* lane\] = r0_;', line)
+            if st:
+                assert int(st.group(3)) == b
+                stored += [(b, 2 * j) for j in range(int(st.group(1)), int(st.group(2)))] + [(b, 2 * j + 1) for j in range(int(st.group(1)), int(st.group(2)))]
+            rs = re.search(r'citw_flag_raise\((\d+),', line)
+            if rs:
+                fl = int(rs.group(1))
+                assert fl in (b, 8 + b), 'wave %d raises flag %d' % (b, fl)
+                for slot in stored:
+                    m_flag.setdefault(slot, fl)          # the FIRST raise behind the store covers the slot
+        post = f.split('CITW_TEAM_BARRIER1()')[1]
+        last_y = None
+        for line in post.splitlines():
+            sy = re.search(r'g_y\[CITW_YOFF \+ (\d+)\] = ', line)
+            if sy:
+                last_y = int(sy.group(1))
+            rp = re.search(r'citw_pflag_raise\((\d+), \(.*\) \* 16u \+ (\d+)u\)', line)
+            if rp:
+                assert int(rp.group(1)) == b and last_y is not None
+                y_pub[last_y] = (b, int(rp.group(2)))
+                last_y = None
+    assert m_flag, 'no shared libm results found'
+    # ---- consumers
+    for f in funcs:
+        b = int(re.match(r'static __device__ CITW_EVAL_INLINE double citw_\w+_team_eval_w(\d+)\(', f).group(1))
+        pre, post = f.split('CITW_TEAM_BARRIER1()')
+        post = post.split('CITW_TEAM_BARRIER2()')[0]
+        assert 'g_f[' not in pre, 'wave %d stores a derivative in front of B1' % b
+        waited = set()
+        fenced = True
+        for line in pre.splitlines():
+            if re.search(r'g_m\[CITW_MROW\(%d\)\]\[2 \* lane\] = ' % b, line) or re.search(r'g_m\[CITW_MROW\(%d\)\]\[\d+\] = ' % b, line):
+                fenced = False
+            if 'CITW_WAVE_FENCE()' in line:
+                fenced = True
+            for w in re.finditer(r'citw_flag_wait(?:_load)?\((\d+),', line):
+                waited.add(int(w.group(1)))
+            for r in re.finditer(r'(?<![\w.])(?:&)?g_m\[CITW_MROW\((\d+)\)\]\[(\d+)\](?!\s*=[^=])', line):
+                q, sl = int(r.group(1)), int(r.group(2))
+                if sl >= 48:
+                    continue                      # (argument slots: written and read by their own wavefront)
+                if q == b:
+                    assert fenced, 'wave %d reads its own libm result %d without a wavefront fence behind the store' % (b, sl)
+                    continue
+                fl = m_flag[(q, sl)]
+                assert fl in waited or (fl == 8 + q and q in waited), 'wave %d reads g_m[%d][%d] in front of B1 without a wait on flag %d (waited: %s)' % (b, q, sl, fl, sorted(waited))
+        pwaited = {}
+        for line in post.splitlines():
+            for w in re.finditer(r'citw_pflag_wait_load\((\d+), \(.*?\) \* 16u \+ (\d+)u, &g_y\[CITW_YOFF \+ (\d+)\]\)', line):
+                q, k, sl = int(w.group(1)), int(w.group(2)), int(w.group(3))
+                assert y_pub[sl][0] == q and k >= y_pub[sl][1], 'wave %d waits for g_y[%d] on (%d, %d), published as %s' % (b, sl, q, k, y_pub[sl])
+                pwaited[q] = max(pwaited.get(q, 0), k)
+            for r in re.finditer(r'(?<![&\w])g_y\[CITW_YOFF \+ (\d+)\](?!\s*=[^=])', line):
+                sl = int(r.group(1))
+                q, k = y_pub[sl]
+                assert q == b or pwaited.get(q, 0) >= k, 'wave %d reads g_y[%d] behind B1 without the producer\'s flag (%d, %d)' % (b, sl, q, k)
