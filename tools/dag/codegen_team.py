@@ -63,6 +63,7 @@ SHARE_SEARCH = int(os.environ.get('CITW_TEAM_SHARE_SEARCH', 1))    # 1: ... and 
 SHARE_1D_WAVE = int(os.environ.get('CITW_TEAM_SHARE_1D_WAVE', 3))   # ... this helper
 SHARE_1D = int(os.environ.get('CITW_TEAM_SHARE_1D', 1))            # 1: ... and the second pass of the 1-D interpolation (16 lanes per episode) runs on wave 3 beside wave 1's first
 SHARE_2D = int(os.environ.get('CITW_TEAM_SHARE_2D', 1))            # 1: with several episodes per team (lane groups) the passes of round 1's 2-D interpolation are shared with helper waves 2, 4, 6 (CITW_L2_SHARE)
+H1D_WAVE = int(os.environ.get('CITW_TEAM_H1D_WAVE', 1))               # ... this helper
 OFFLOAD_1D = int(os.environ.get('CITW_TEAM_OFFLOAD_1D', 1))          # 1: the 1-D interpolation pass of round 1 runs on helper wave 1 (after wave 0's index search, by flag) beside wave 0's 2-D pass
 SPREAD_MIN = float(os.environ.get('CITW_TEAM_SPREAD_MIN', 0))         # with SPREAD_INPUTS: only input cones at least this heavy (units) leave wave 0
 SIMD_PAIRS = int(os.environ.get('CITW_TEAM_SIMD_PAIRS', 0))            # 1: the balancer counts the load of a SIMD (waves b and b + 4 share one) instead of a wave's
@@ -220,7 +221,7 @@ class TeamGen(codegen.Gen):
             AE = self.closure(seeds, S0)
             load[EW] += sum(cost(m) for m in AE if m not in have[EW]) + CHAIN_COST
             have[EW] |= AE
-        self.h1d = 1 if (OFFLOAD_1D and K > 2 and self.rounds[0]['L1']) else None
+        self.h1d = min(H1D_WAVE, K - 1) if (OFFLOAD_1D and K > 2 and self.rounds[0]['L1']) else None
         self.l2_helpers = L2_WAVES if (SHARE_2D and K >= 7 and self.h1d is not None and self.rounds[0]['L2']) else []
         if self.h1d is not None:
             load[self.h1d] += 220.0            # the 1-D pass it takes over from wave 0

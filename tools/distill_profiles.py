@@ -4,7 +4,7 @@
 import json, shutil, sys
 tag, series = sys.argv[1], sys.argv[2]
 O, P = 'gpurun_out/' + tag, 'profiles'
-for n in ('serl50', 'total512', 'serl10', 'serl10_pop128', 'pop64', 'pop128', 'pop341', 'mixed', 'rccl1'):
+for n in ('serl50', 'total512', 'serl10', 'serl10_pop128', 'pop64', 'pop128', 'pop341', 'mixed', 'mixed_total2048', 'rccl1'):
     line = [l for l in open('%s/bench_%s.json' % (O, n)) if l.startswith('{')][-1]
     open('%s/%s_bench_%s.json' % (P, series, n), 'w').write(line)
 for n in ('serl50', 'serl10_pop128', 'pop512'):
@@ -36,9 +36,11 @@ pmc['issue'] = dict(
          'the actor wavefront is parked ~80 % of its time by design)',
     simd_issue_frac=2 * sq['SQ_ACTIVE_INST_ANY'] / wc,
     valu_per_env_step=sq['SQ_INSTS_VALU'] / steps, salu_per_env_step=sq['SQ_INSTS_SALU'] / steps, lds_per_env_step=sq['SQ_INSTS_LDS'] / steps,
-    issue_floor_us_per_env_step=cp['issue_floor_us_per_env_step'], dependency_floor_us_per_env_step=cp['dependency_floor_us_per_env_step'],
-    measured_us_per_env_step=b['t_step_us'], issue_floor_frac=cp['issue_floor_us_per_env_step'] / b['t_step_us'],
-    frac_note='issue floor (minimal instruction count of the model DAG x 4 cycles over 4 SIMDs, tools/dag/critical_path.py) / measured time '
+    issue_floor_us_per_env_step=cp['issue_floor_trimmed_us_per_env_step'], issue_floor_full_dag_us_per_env_step=cp['issue_floor_us_per_env_step'],
+    dependency_floor_us_per_env_step=cp['dependency_floor_us_per_env_step'],
+    measured_us_per_env_step=b['t_step_us'], issue_floor_frac=cp['issue_floor_trimmed_us_per_env_step'] / b['t_step_us'],
+    issue_floor_frac_full_dag=cp['issue_floor_us_per_env_step'] / b['t_step_us'],
+    frac_note='issue floor (minimal instruction count of what the trimmed flight condition executes x 4 cycles over 4 SIMDs, tools/dag/critical_path.py; `_full_dag`: every node) / measured time '
               'per env step; the dependency floor weights a look-up with its own dependent chain (three LDS round trips, two divisions)',
     source='profiles/%s_pmc.json, profiles/%s_critical_path.json, profiles/%s_valu_latency.json' % (series, series, series))
 json.dump(pmc, open('%s/%s_pmc.json' % (P, series), 'w'), indent=1)
