@@ -204,7 +204,10 @@ int serl_ctx_load_build(serl_ctx *ctx, int slot, const serl_build_desc *build);
 /* Development overrides, read from the environment ONCE, by serl_ctx_create (the only getenv of the library):
  *   SERL_KERNEL=team|team2|team4|wave|half   kernel family for descriptors with kernel_hint == SERL_KERNEL_AUTO
  *   SERL_WAVES_PER_BLOCK=n                   wavefronts per workgroup of the one-wavefront kernels
- *   SERL_PROFILE=1                           cycle counters for serl_debug_profile */
+ *   SERL_PROFILE=1                           cycle counters for serl_debug_profile
+ *   SERL_SPLIT_ACTOR=1                       one-episode teams with a streamed actor (hidden > 64): two actor wavefronts share the forward pass
+ *   SERL_JITTER_SEED=n, SERL_JITTER_SITES=m  acted on only by the TEST-ONLY stress build of the team kernels (libserl_amd_jitter.so:
+ *                                            poisoned LDS blackboards, seeded pauses around every hand-over; the product ignores them) */
 
 /* One population evaluation: all episodes of the descriptor, one fused kernel launch per call. */
 int serl_rollout(serl_ctx *ctx, const serl_rollout_desc *desc, void *stream);
