@@ -612,6 +612,110 @@ static __device__ void serl_actor_forward_small(const serl_rollout_desc &dd, con
   }
 }
 
+// ... and for 64 < H <= 128 (SERL10's 72, the TD3 actor's 96; round 4): H a compile-time constant, a layer walked in chunks of CH
+// columns with compile-time bounds, BOTH row sets (rows 0..63 on the lanes, rows 64..H-1 on the first lanes) fed by the same eight
+// broadcasts, the next chunk's weights in flight behind the current one's arithmetic: 4 x CH registers of weights (96 at CH = 24), so it
+// lives inside the 256 registers a team kernel leaves its actor wavefront (a first version held whole rows: 1.7 x faster than
+// serl_actor_forward_wave alone on a SIMD, and slower than it inside the kernel, where it spilled -- profiles/r04_experiments.md).
+// Same dot products (four interleaved fma partial sums over ascending columns), same LayerNorm sums (serl_tree_sum_rt): bit-identical
+// to serl_actor_forward_wave (= the oracle's arithmetic).
+template <int H, int CH, class Sync>
+static __device__ void serl_actor_forward_chunked(const serl_rollout_desc &dd, const float *w_generic, const float obs[7],
+                                                  float act_out[3], Sync &sync)
+{
+  static_assert(H > 64 && H <= 128 && CH % 8 == 0 && H % CH == 0 && 64 % 8 == 0, "two row sets; whole chunks; batches of eight broadcasts");
+  constexpr int NCH = H / CH, Hb = H - 64;
+  const int L = __builtin_amdgcn_readfirstlane(dd.num_layers), act = __builtin_amdgcn_readfirstlane(dd.activation);
+  serl_gptr w = (serl_gptr)w_generic;
+  const int lane = threadIdx.x & 63;
+  const int i0 = lane, i1 = lane < Hb ? lane + 64 : H - 1, io = lane < 3 ? lane : 2;
+  constexpr size_t lstride = (size_t)H * H + 3 * (size_t)H;
+  serl_gptr hid = w + (size_t)H * 7 + H, outl = hid + (size_t)L * lstride;
+  const int nchunks = (L + 1) * NCH;
+  float na[CH], nb[CH];                                   // the chunk in flight
+  float nbi0 = 0.0f, nbi1 = 0.0f, ngm0 = 0.0f, ngm1 = 0.0f, nbt0 = 0.0f, nbt1 = 0.0f;
+  auto load = [&](float (&dst)[CH], serl_gptr row) {
+#pragma unroll
+    for (int q = 0; q < CH / 4; ++q) {
+      const serl_v4f v = *(serl_gptr4)(row + 4 * q);
+      dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+    }
+  };
+  auto issue = [&](const int l, const int c) {            // chunk c of layer l (l == L: the output layer, rows 0..2 on lanes 0..2)
+    if (l < L) {
+      serl_gptr Wl = hid + (size_t)l * lstride;
+      load(na, Wl + (size_t)i0 * H + c * CH);
+      load(nb, Wl + (size_t)i1 * H + c * CH);
+      if (c == 0) {
+        serl_gptr bl = Wl + (size_t)H * H;
+        nbi0 = bl[i0]; ngm0 = bl[H + i0]; nbt0 = bl[2 * H + i0];
+        nbi1 = bl[i1]; ngm1 = bl[H + i1]; nbt1 = bl[2 * H + i1];
+      }
+    } else {
+      load(na, outl + (size_t)io * H + c * CH);
+      if (c == 0) nbi0 = (outl + (size_t)3 * H)[io];
+    }
+  };
+  issue(0, 0);
+  float ha, hb;
+  {
+    serl_gptr b = w + (size_t)H * 7;
+    float wa[7], wb[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) { wa[j] = w[(size_t)i0 * 7 + j]; wb[j] = w[(size_t)i1 * 7 + j]; }
+    ha = serl_act(serl_dot7(b[i0], wa, obs), act);
+    hb = serl_act(serl_dot7(b[i1], wb, obs), act);
+  }
+  sync(0, nchunks + 1);
+  for (int l = 0; l <= L; ++l) {
+    float pa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float bi0 = 0.0f, bi1 = 0.0f, gm0 = 0.0f, gm1 = 0.0f, bt0 = 0.0f, bt1 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float wa[CH], wb[CH];
+#pragma unroll
+      for (int q = 0; q < CH; ++q) { wa[q] = na[q]; wb[q] = nb[q]; }
+      if (c == 0) { bi0 = nbi0; bi1 = nbi1; gm0 = ngm0; gm1 = ngm1; bt0 = nbt0; bt1 = nbt1; }
+      __builtin_amdgcn_sched_barrier(0);                  // (ONE chunk in flight: the scheduler may not pull a later chunk's loads up here)
+      if (c + 1 < NCH) issue(l, c + 1);
+      else if (l < L) issue(l + 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q0 = 0; q0 < CH; q0 += 8) {                // eight broadcasts, then the multiply-adds of both row sets
+        float b[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int j = c * CH + q0 + q;                  // (compile-time: the loops are unrolled)
+          b[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(j < 64 ? ha : hb), j & 63));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pa[q & 3] = __builtin_fmaf(wa[q0 + q], b[q], pa[q & 3]);
+        if (l < L) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) pb[q & 3] = __builtin_fmaf(wb[q0 + q], b[q], pb[q & 3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      sync(l * NCH + c + 1, nchunks + 1);
+    }
+    const float acc0 = bi0 + ((pa[0] + pa[1]) + (pa[2] + pa[3]));
+    if (l < L) {
+      const float acc1 = bi1 + ((pb[0] + pb[1]) + (pb[2] + pb[3]));
+      const float mean = serl_tree_sum_rt(acc0, acc1, 64, Hb, lane) / (float)H;
+      const float d0 = acc0 - mean, d1 = acc1 - mean;
+      const float var = serl_tree_sum_rt(d0 * d0, d1 * d1, 64, Hb, lane);
+      const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
+      ha = serl_act(gm0 * d0 / den + bt0, act);
+      hb = serl_act(gm1 * d1 / den + bt1, act);
+    } else {
+      const float t = det_tanhf(acc0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, i);
+    }
+  }
+}
+
 // ---- LDS-resident actor (team kernels: one episode per workgroup, ~23 KB of LDS free beside the model tables) ----
 // The member's weights are staged once per episode into LDS in the order the lanes consume them, so a step reads no
 // weight from L2/HBM at all (a lone wavefront per SIMD has nothing to hide that latency with -- measured 3 k cycles per
@@ -919,6 +1023,13 @@ static __device__ __forceinline__ void serl_actor_forward(const serl_rollout_des
   const int H = __builtin_amdgcn_readfirstlane(dd.hidden);
   if (H == 32) serl_actor_forward_small<32>(dd, w, obs, act_out, sync);
   else if (H == 64) serl_actor_forward_small<64>(dd, w, obs, act_out, sync);
+#ifndef SERL_NO_CHUNKED_ACTOR
+#ifndef SERL_ACTOR_CHUNK
+#define SERL_ACTOR_CHUNK 8      // (r04 session u, H = 72 / 96 one per team: 8 = 20.5 / 19.9 us per env step with 48 spilled registers in the streamed-actor kernel, 24 = 20.7 / 20.0 with 89)
+#endif
+  else if (H == 72) serl_actor_forward_chunked<72, SERL_ACTOR_CHUNK>(dd, w, obs, act_out, sync);      // SERL10 (logs/wandb/run-20220913_165505-12zowviu_SERL10/files/config.yaml:72-74)
+  else if (H == 96) serl_actor_forward_chunked<96, SERL_ACTOR_CHUNK>(dd, w, obs, act_out, sync);      // the TD3 actor
+#endif
   else serl_actor_forward_wave(dd, w, obs, act_out, sync);
 }
 static __device__ __forceinline__ void serl_actor_forward(const serl_rollout_desc &dd, const float *w, const float obs[7],

@@ -6,6 +6,7 @@
 #define CITW_M_ROWS 32            // libm result rows: one per (team wavefront, episode)
 #define CITW_OUT2_ROWS 1
 #define CITW_INV_SLOTS 8
+#define SERL_NO_CHUNKED_ACTOR 1      // (these kernels carry H = 32 actors only: serl_capi.hip)
 #include "citation_wave.h"
 #include "rollout_device.h"
 #include "gen/citation_gust_wave.inc"   // look-up descriptor tables (shared with the one-wave kernels)

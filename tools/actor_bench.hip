@@ -21,6 +21,21 @@ __global__ void __launch_bounds__(64) bench(serl_rollout_desc d, const float *w,
   if (threadIdx.x == 0) { cyc[0] = (t1 - t0) / reps; out[0] = a[0]; }
 }
 
+// the same with the generic streaming forward (run-time shape, 32-column chunks): what shapes without a specialised path use
+__global__ void __launch_bounds__(64) bench_generic(serl_rollout_desc d, const float *w, int reps, unsigned long long *cyc, float *out)
+{
+  float o[7] = {0.01f, -0.02f, 0.005f, 0.1f, -0.05f, 0.02f, 0.03f}, a[3] = {0, 0, 0};
+  SerlNoSync ns;
+  serl_actor_forward_wave(d, w, o, a, ns);
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int r = 0; r < reps; ++r) {
+    o[0] = a[0] * 0.01f;
+    serl_actor_forward_wave(d, w, o, a, ns);
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) { cyc[0] = (t1 - t0) / reps; out[0] = a[0]; }
+}
+
 int main()
 {
   const int shapes[][2] = {{32, 0}, {32, 2}, {64, 0}, {72, 0}, {72, 2}, {96, 0}, {96, 2}, {128, 0}};
@@ -39,7 +54,10 @@ int main()
     hipLaunchKernelGGL(bench, dim3(1), dim3(64), 0, 0, d, dw, 200, dc, dout);
     unsigned long long c = 0; float o = 0;
     hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost); hipMemcpy(&o, dout, 4, hipMemcpyDeviceToHost);
-    printf("{\"hidden\": %d, \"activation\": %d, \"cycles_per_forward\": %llu, \"out0\": %g}\n", H, act, c, o);
+    hipLaunchKernelGGL(bench_generic, dim3(1), dim3(64), 0, 0, d, dw, 200, dc, dout);
+    unsigned long long cg = 0; float og = 0;
+    hipMemcpy(&cg, dc, 8, hipMemcpyDeviceToHost); hipMemcpy(&og, dout, 4, hipMemcpyDeviceToHost);
+    printf("{\"hidden\": %d, \"activation\": %d, \"cycles_per_forward\": %llu, \"out0\": %g, \"cycles_per_forward_generic\": %llu, \"same_bits_as_generic\": %d}\n", H, act, c, o, cg, o == og);
     hipFree(dw); hipFree(dout); hipFree(dc);
   }
   return 0;
