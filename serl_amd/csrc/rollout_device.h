@@ -170,8 +170,10 @@ struct SerlBarrierCredit {
 #if defined(CITW_JITTER) && CITW_JITTER
   unsigned salt = 0;      // the env step (jitter hash only)
 #endif
+  bool defer_last = false;      // the last piece pays nothing: the caller hands its result on first and pays the rest with (0, 1)
   __device__ __forceinline__ void operator()(int piece, int n)
   {
+    if (defer_last && piece + 1 == n) return;
     const int target = per_step * (piece + 1) / n;
     while (done < target) { SERL_CREDIT_JIT(*this); __builtin_amdgcn_s_barrier(); ++done; }
   }
