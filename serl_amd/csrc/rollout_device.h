@@ -38,11 +38,16 @@ struct RolloutArgs {
  *   q = expm1(r) by the Taylor polynomial through r^13/13! in Estrin form (pairs, quads, octets);
  *   tanh = q/(q+2) if k == 0 else 1 - 2/(2^k (q+1) + 1);   expm1 = q if k == 0 else 2^k (q+1) - 1;
  * the f64 result (error ~1e-16) is rounded to f32 once. */
-static DET_FN double det_expm1_reduced(double z, long long *kout)
+// SIGN: what the caller knows about z (+1: z >= 0, tanh; -1: z <= 0, the ELU branch).  |k| stays below 151 for every argument the
+// callers pass (z in [0, 40] or [-104, 0]), so the specification's round-half-away through (long long) is ONE v_cvt_i32_f64 (truncation,
+// like the cast) on the branch the sign selects and k comes back through v_cvt_f64_i32 -- the same integers, without the 64-bit
+// conversion sequences (two of ~14 instructions under exec masks, and five for (double)k) the generic form compiles to.
+template <int SIGN>
+static DET_FN double det_expm1_reduced(double z, int *kout)
 {
   const double INVLN2 = 1.4426950408889634, LN2_HI = 0.6931471803691238, LN2_LO = 1.9082149292705877e-10;
   const double v = z * INVLN2;
-  const long long k = v < 0.0 ? -(long long)(0.5 - v) : (long long)(v + 0.5);
+  const int k = SIGN < 0 ? -(int)(0.5 - v) : (int)(v + 0.5);
   const double kd = (double)k;
   const double r = (z - kd * LN2_HI) - kd * LN2_LO;
   /* expm1(r) - r = r^2 P(r), P of degree 11 with the Taylor coefficients 1/2! .. 1/13!, in Estrin form (dependency depth
@@ -65,8 +70,8 @@ static DET_FN float det_tanhf(float xf)
   // branch-free over the lanes of a wavefront (one division instead of one per divergent branch); per lane the operations
   // are those of the specification:  k == 0: q / (q + 2);  else 1 - 2 / (2^k (q + 1) + 1);  |x| > 20: 1
   const double axc = ax > 20.0 ? 20.0 : ax;
-  long long k;
-  const double q = det_expm1_reduced(axc + axc, &k);
+  int k;
+  const double q = det_expm1_reduced<1>(axc + axc, &k);
   const bool small = k == 0;
   const double num = small ? q : 2.0;
   const double den = small ? q + 2.0 : DET_POW2(k) * (q + 1.0) + 1.0;
@@ -81,8 +86,8 @@ static DET_FN float det_expm1f_neg(float xf)     /* x <= 0 (the ELU branch) */
   if (xf != xf) return xf;
   const double x = (double)xf;
   if (x < -104.0) return -1.0f;
-  long long k;
-  const double q = det_expm1_reduced(x, &k);
+  int k;
+  const double q = det_expm1_reduced<-1>(x, &k);
   return (float)(k == 0 ? q : DET_POW2(k) * (q + 1.0) - 1.0);
 }
 
@@ -276,6 +281,37 @@ static __device__ __forceinline__ float serl_tree_sum(float x, int lane)      //
 typedef const __attribute__((address_space(1))) float *serl_gptr;   // weights live in global memory (HBM/L2)
 typedef float serl_v4f __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) serl_v4f *serl_gptr4;
+
+// ---- the previous layer broadcast through an LDS row instead of lane by lane (round 4, session y) ---------------------------
+// v_readlane costs a VALU issue slot per column (H of them per layer, beside H / 2 packed multiply-adds); the actor wavefront of
+// a team kernel shares its SIMD with a team wavefront, so its issue slots are the team's.  Here the lanes store the layer into a
+// row of LDS that belongs to this wavefront alone and read it back four columns at a time with one ds_read_b128 at a wave-uniform
+// address (a broadcast: no bank conflict); the multiply-adds are the same four interleaved partial sums over ascending columns,
+// written as two packed pairs (v_pk_fma_f32: one IEEE fma per half) -- bit-identical to serl_mac4_lanes / the readlane chunks.
+// The wavefront-scope fences order the lanes' stores and loads for the COMPILER (the hardware keeps a wavefront's LDS operations
+// in order; see CITW_WAVE_FENCE in citation_wave.h for what happens without them).
+#ifndef SERL_ACTOR_LDS_BCAST
+#define SERL_ACTOR_LDS_BCAST 1
+#endif
+typedef float serl_v2f __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) serl_v4f *serl_lrow4;
+#define SERL_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+
+// The row's LDS address in a register the optimiser cannot see through: the reads become ds_read_b128 v, base offset:16 * q (a row
+// above 64 KB is out of reach of the 16-bit offset field, and a known address is materialised again for every single read)
+static __device__ __forceinline__ unsigned serl_lds_row_base(const float *hx)
+{
+  unsigned b = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) float *)hx;
+  asm volatile("" : "+v"(b));
+  return b;
+}
+// p01 = (p0, p1), p23 = (p2, p3) += w[0..3] * hx[j .. j + 3]   (j a multiple of 4, wave-uniform)
+static __device__ __forceinline__ void serl_pk_mac4(serl_v2f &p01, serl_v2f &p23, const float *w4, unsigned hxb, int j)
+{
+  const serl_v4f hv = *(serl_lrow4)(unsigned long long)(hxb + 4u * (unsigned)j);
+  p01 = __builtin_elementwise_fma(serl_v2f{w4[0], w4[1]}, serl_v2f{hv.x, hv.y}, p01);
+  p23 = __builtin_elementwise_fma(serl_v2f{w4[2], w4[3]}, serl_v2f{hv.z, hv.w}, p23);
+}
 
 // 32 consecutive weights of one row, as 8 dwordx4 loads issued together (zeros past column H)
 static __device__ __forceinline__ void serl_load_chunk(float (&wv)[32], serl_gptr row, int jc, int H)
@@ -621,9 +657,10 @@ static __device__ void serl_actor_forward_small(const serl_rollout_desc &dd, con
 // serl_actor_forward_wave alone on a SIMD, and slower than it inside the kernel, where it spilled -- profiles/r04_experiments.md).
 // Same dot products (four interleaved fma partial sums over ascending columns), same LayerNorm sums (serl_tree_sum_rt): bit-identical
 // to serl_actor_forward_wave (= the oracle's arithmetic).
-template <int H, int CH, class Sync>
+// BC: the previous layer goes through the LDS row hx (128 floats, this wavefront's own) instead of v_readlane (above)
+template <int H, int CH, bool BC, class Sync>
 static __device__ void serl_actor_forward_chunked(const serl_rollout_desc &dd, const float *w_generic, const float obs[7],
-                                                  float act_out[3], Sync &sync)
+                                                  float act_out[3], Sync &sync, float *hx = nullptr)
 {
   static_assert(H > 64 && H <= 128 && CH % 8 == 0 && H % CH == 0 && 64 % 8 == 0, "two row sets; whole chunks; batches of eight broadcasts");
   constexpr int NCH = H / CH, Hb = H - 64;
@@ -671,7 +708,15 @@ static __device__ void serl_actor_forward_chunked(const serl_rollout_desc &dd, c
   sync(0, nchunks + 1);
   for (int l = 0; l <= L; ++l) {
     float pa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    serl_v2f qa01 = {0.0f, 0.0f}, qa23 = {0.0f, 0.0f}, qb01 = {0.0f, 0.0f}, qb23 = {0.0f, 0.0f};      // (BC: the same sums as packed pairs)
     float bi0 = 0.0f, bi1 = 0.0f, gm0 = 0.0f, gm1 = 0.0f, bt0 = 0.0f, bt1 = 0.0f;
+    unsigned hxb = 0;
+    if constexpr (BC) {      // rows 0..63 from the lanes, rows 64..H-1 from the first lanes (the others repeat row H-1 into slots nobody reads)
+      SERL_WAVE_FENCE();
+      hx[lane] = ha; hx[64 + lane] = hb;
+      SERL_WAVE_FENCE();
+      hxb = serl_lds_row_base(hx);
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       float wa[CH], wb[CH];
@@ -682,6 +727,17 @@ static __device__ void serl_actor_forward_chunked(const serl_rollout_desc &dd, c
       if (c + 1 < NCH) issue(l, c + 1);
       else if (l < L) issue(l + 1, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (BC) {
+#pragma unroll
+        for (int q0 = 0; q0 < CH; q0 += 4) {
+          serl_pk_mac4(qa01, qa23, &wa[q0], hxb, c * CH + q0);
+          serl_pk_mac4(qb01, qb23, &wb[q0], hxb, c * CH + q0);      // (output layer: sums of stale finite weights nobody reads -- cheaper than four selects per chunk)
+        }
+        // the sums are pinned here: nothing in the IR keeps a pure multiply-add in front of the barriers `sync` executes, and sunk to the
+        // layer's end they take every chunk's weights and broadcasts along (through scratch)
+        asm volatile("" : "+v"(qa01), "+v"(qa23), "+v"(qb01), "+v"(qb23));
+        __builtin_amdgcn_sched_barrier(0);                // (as below: one chunk in flight)
+      } else
 #pragma unroll
       for (int q0 = 0; q0 < CH; q0 += 8) {                // eight broadcasts, then the multiply-adds of both row sets
         float b[8];
@@ -700,6 +756,10 @@ static __device__ void serl_actor_forward_chunked(const serl_rollout_desc &dd, c
         __builtin_amdgcn_sched_barrier(0);
       }
       sync(l * NCH + c + 1, nchunks + 1);
+    }
+    if constexpr (BC) {
+      pa[0] = qa01.x; pa[1] = qa01.y; pa[2] = qa23.x; pa[3] = qa23.y;
+      pb[0] = qb01.x; pb[1] = qb01.y; pb[2] = qb23.x; pb[3] = qb23.y;
     }
     const float acc0 = bi0 + ((pa[0] + pa[1]) + (pa[2] + pa[3]));
     if (l < L) {
@@ -766,9 +826,10 @@ static __device__ __forceinline__ void serl_stage_actor_lds(const serl_rollout_d
   for (int t = threadIdx.x; t < 3; t += blockDim.x) dst[4 * H + t] = src[3 * H + t];
 }
 
-template <class Sync>
+// BC: the previous layer goes through the LDS row hx (64 floats, this wavefront's own) instead of v_readlane (above)
+template <bool BC, class Sync>
 static __device__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const float *lw_generic, const float obs[7],
-                                              float act_out[3], Sync &sync)
+                                              float act_out[3], Sync &sync, float *hx = nullptr)
 {
   constexpr int H = SERL_LDS_ACTOR_H;
   const int L = __builtin_amdgcn_readfirstlane(dd.num_layers), act = __builtin_amdgcn_readfirstlane(dd.activation);
@@ -797,7 +858,8 @@ static __device__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const
     }
   };
   CITW_T0();
-  issue(0);
+  if constexpr (!BC) issue(0);      // (BC: a layer's rows are read where they are used -- the actor wavefront has a whole env step for a fifth of a
+                                    // step's work, what counts is its issue slots: no double buffer, no 35 register moves per layer)
   float h;
   {
     float acc = lw[7 * H + i0], w0[7];
@@ -809,13 +871,25 @@ static __device__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const
   CITW_T(22);
   sync(0, L + 2);
   for (int l = 0; l <= L; ++l) {
+    if constexpr (BC) issue(l);
     float row[H];
 #pragma unroll
     for (int j = 0; j < H; ++j) row[j] = nrow[j];
     float acc = nbi;
     const float gm = ngm, bt = nbt;
-    if (l < L) issue(l + 1);
-    acc = serl_mac4_lanes<H>(acc, row, h);
+    if constexpr (BC) {
+      SERL_WAVE_FENCE();
+      hx[lane] = h;                                        // (lanes 32..63 repeat row 31 into slots nobody reads)
+      SERL_WAVE_FENCE();
+      const unsigned hxb = serl_lds_row_base(hx);
+      serl_v2f p01 = {0.0f, 0.0f}, p23 = {0.0f, 0.0f};
+#pragma unroll
+      for (int q = 0; q < H / 4; ++q) serl_pk_mac4(p01, p23, &row[4 * q], hxb, 4 * q);
+      acc = acc + ((p01.x + p01.y) + (p23.x + p23.y));
+    } else {
+      if (l < L) issue(l + 1);
+      acc = serl_mac4_lanes<H>(acc, row, h);
+    }
     CITW_T(23);
     if (l < L) {
       float mean = serl_tree_sum<H>(acc, lane);
@@ -1018,9 +1092,9 @@ static __device__ void serl_actor_forward_quarter32(const serl_rollout_desc &dd,
 }
 
 
-template <class Sync>
+template <bool BC = false, class Sync>
 static __device__ __forceinline__ void serl_actor_forward(const serl_rollout_desc &dd, const float *w, const float obs[7],
-                                                          float act_out[3], Sync &sync)
+                                                          float act_out[3], Sync &sync, float *hx = nullptr)
 {
   const int H = __builtin_amdgcn_readfirstlane(dd.hidden);
   if (H == 32) serl_actor_forward_small<32>(dd, w, obs, act_out, sync);
@@ -1029,8 +1103,8 @@ static __device__ __forceinline__ void serl_actor_forward(const serl_rollout_des
 #ifndef SERL_ACTOR_CHUNK
 #define SERL_ACTOR_CHUNK 8      // (r04 session u, H = 72 / 96 one per team: 8 = 20.5 / 19.9 us per env step with 48 spilled registers in the streamed-actor kernel, 24 = 20.7 / 20.0 with 89)
 #endif
-  else if (H == 72) serl_actor_forward_chunked<72, SERL_ACTOR_CHUNK>(dd, w, obs, act_out, sync);      // SERL10 (logs/wandb/run-20220913_165505-12zowviu_SERL10/files/config.yaml:72-74)
-  else if (H == 96) serl_actor_forward_chunked<96, SERL_ACTOR_CHUNK>(dd, w, obs, act_out, sync);      // the TD3 actor
+  else if (H == 72) serl_actor_forward_chunked<72, SERL_ACTOR_CHUNK, BC>(dd, w, obs, act_out, sync, hx);      // SERL10 (logs/wandb/run-20220913_165505-12zowviu_SERL10/files/config.yaml:72-74)
+  else if (H == 96) serl_actor_forward_chunked<96, SERL_ACTOR_CHUNK, BC>(dd, w, obs, act_out, sync, hx);      // the TD3 actor
 #endif
   else serl_actor_forward_wave(dd, w, obs, act_out, sync);
 }
@@ -1038,13 +1112,13 @@ static __device__ __forceinline__ void serl_actor_forward(const serl_rollout_des
                                                           float act_out[3])
 {
   SerlNoSync none;
-  serl_actor_forward(dd, w, obs, act_out, none);
+  serl_actor_forward<false>(dd, w, obs, act_out, none);
 }
 static __device__ __forceinline__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const float *lw, const float obs[7],
                                                               float act_out[3])
 {
   SerlNoSync none;
-  serl_actor_forward_lds(dd, lw, obs, act_out, none);
+  serl_actor_forward_lds<false>(dd, lw, obs, act_out, none);
 }
 
 static __device__ __forceinline__ double serl_clip(double v, double lo, double hi)
