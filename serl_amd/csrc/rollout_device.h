@@ -47,8 +47,14 @@ static DET_FN double det_expm1_reduced(double z, int *kout)
 {
   const double INVLN2 = 1.4426950408889634, LN2_HI = 0.6931471803691238, LN2_LO = 1.9082149292705877e-10;
   const double v = z * INVLN2;
+#if defined(SERL_DET_K64) && SERL_DET_K64      // (A/B builds: the specification's form as written)
+  const long long k64 = v < 0.0 ? -(long long)(0.5 - v) : (long long)(v + 0.5);
+  const int k = (int)k64;
+  const double kd = (double)k64;
+#else
   const int k = SIGN < 0 ? -(int)(0.5 - v) : (int)(v + 0.5);
   const double kd = (double)k;
+#endif
   const double r = (z - kd * LN2_HI) - kd * LN2_LO;
   /* expm1(r) - r = r^2 P(r), P of degree 11 with the Taylor coefficients 1/2! .. 1/13!, in Estrin form (dependency depth
    * 7 instead of 24: a lone GPU wavefront waits out every dependent operation) */
@@ -161,7 +167,7 @@ static __device__ __forceinline__ float serl_act(float v, int act)
 // Progress callback of the actor forward: called after piece `piece` of `n` (input layer, then every hidden layer /
 // weight chunk, then the output layer).  The rollout kernels whose wavefront owns a whole episode pass nothing; the team
 // kernels' ACTOR WAVEFRONT uses it to pay its share of the workgroup barriers while it works (SerlBarrierCredit).
-struct SerlNoSync { __device__ __forceinline__ void operator()(int, int) const {} };
+struct SerlNoSync { __device__ __forceinline__ void operator()(int, int) const {} __device__ __forceinline__ void start(int) const {} };
 // The actor wavefront of a team runs beside the wavefronts that integrate the model (rollout_team.inc); the hardware
 // barrier counts every wavefront of the workgroup, so it executes the step's `per_step` barriers too -- spread evenly
 // over the pieces of its forward pass, so that it is early at every one of them and never holds the team up.
@@ -176,10 +182,13 @@ struct SerlBarrierCredit {
   unsigned salt = 0;      // the env step (jitter hash only)
 #endif
   bool defer_last = false;      // the last piece pays nothing: the caller hands its result on first and pays the rest with (0, 1)
+  int inc = 0;                  // per_step / n in 16.16 fixed point: a forward pass divides once (start), not per piece (the chunked passes have 37)
+  __device__ __forceinline__ void start(int n) { inc = (per_step << 16) / n; }      // every forward pass calls it in front of its first piece
   __device__ __forceinline__ void operator()(int piece, int n)
   {
     if (defer_last && piece + 1 == n) return;
-    const int target = per_step * (piece + 1) / n;
+    // (any non-decreasing schedule that stays at or below per_step is right: the caller pays the remainder with (0, 1) -- n == 1, `all the rest`)
+    const int target = n == 1 ? per_step : ((piece + 1) * inc) >> 16;
     while (done < target) { SERL_CREDIT_JIT(*this); __builtin_amdgcn_s_barrier(); ++done; }
   }
 };
@@ -189,9 +198,11 @@ struct SerlBarrierCredit {
 struct SerlBarrierCreditPart {
   SerlBarrierCredit &base;
   int lo, hi;
+  int inc = 0;
+  __device__ __forceinline__ void start(int n) { inc = ((hi - lo) << 16) / n; }
   __device__ __forceinline__ void operator()(int piece, int n)
   {
-    const int target = lo + (hi - lo) * (piece + 1) / n;
+    const int target = lo + (((piece + 1) * inc) >> 16);
     while (base.done < target) { SERL_CREDIT_JIT(base); __builtin_amdgcn_s_barrier(); ++base.done; }
   }
 };
@@ -426,6 +437,7 @@ static __device__ void serl_actor_forward_wave(const serl_rollout_desc &dd, cons
     h0a = serl_act(serl_dot7(b[i0], wa, obs), act);
     if (two) h0b = serl_act(serl_dot7(b[i1], wb, obs), act);
   }
+  sync.start(nchunks + 1);
   sync(0, nchunks + 1);
   float bi0 = 0.0f, bi1 = 0.0f, gm0 = 0.0f, gm1 = 0.0f, bt0 = 0.0f, bt1 = 0.0f;
   float p0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, p1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -545,6 +557,7 @@ static __device__ void serl_actor_forward_split(const serl_rollout_desc &dd, con
     const float mine = serl_act(serl_dot7(b[im], wa, obs), act);
     exchange(0, mine, h0a, h0b);
   }
+  sync.start(L + 2);
   sync(0, L + 2);
   float bim = 0.0f, gm0 = 0.0f, gm1 = 0.0f, bt0 = 0.0f, bt1 = 0.0f;
   float p0[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -623,6 +636,7 @@ static __device__ void serl_actor_forward_small(const serl_rollout_desc &dd, con
     h = serl_act(acc, act);
   }
   CITW_T(22);
+  sync.start(L + 2);
   sync(0, L + 2);
   for (int l = 0; l <= L; ++l) {
     float row[H];
@@ -680,19 +694,20 @@ static __device__ void serl_actor_forward_chunked(const serl_rollout_desc &dd, c
       dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
     }
   };
-  auto issue = [&](const int l, const int c) {            // chunk c of layer l (l == L: the output layer, rows 0..2 on lanes 0..2)
-    if (l < L) {
-      serl_gptr Wl = hid + (size_t)l * lstride;
-      load(na, Wl + (size_t)i0 * H + c * CH);
-      load(nb, Wl + (size_t)i1 * H + c * CH);
-      if (c == 0) {
-        serl_gptr bl = Wl + (size_t)H * H;
+  // chunk c of layer l (l == L: the output layer, rows 0..2 on lanes 0..2).  BOTH row sets are loaded on both sides of l < L (the
+  // output layer reads its row twice): a register that one side of a branch leaves alone is copied on the other -- eight moves per
+  // chunk -- and the rows are 32-bit element offsets from the wave-uniform `hid` (one VGPR per row set instead of a 64-bit pointer).
+  auto issue = [&](const int l, const int c) {
+    const unsigned lo = (unsigned)(l < L ? l : L) * (unsigned)lstride;
+    const unsigned oa = lo + (unsigned)(l < L ? i0 : io) * (unsigned)H, ob = lo + (unsigned)(l < L ? i1 : io) * (unsigned)H;
+    load(na, hid + oa + c * CH);
+    load(nb, hid + ob + c * CH);
+    if (c == 0) {
+      if (l < L) {
+        serl_gptr bl = hid + lo + H * H;
         nbi0 = bl[i0]; ngm0 = bl[H + i0]; nbt0 = bl[2 * H + i0];
         nbi1 = bl[i1]; ngm1 = bl[H + i1]; nbt1 = bl[2 * H + i1];
-      }
-    } else {
-      load(na, outl + (size_t)io * H + c * CH);
-      if (c == 0) nbi0 = (outl + (size_t)3 * H)[io];
+      } else nbi0 = (outl + (size_t)3 * H)[io];
     }
   };
   issue(0, 0);
@@ -705,6 +720,7 @@ static __device__ void serl_actor_forward_chunked(const serl_rollout_desc &dd, c
     ha = serl_act(serl_dot7(b[i0], wa, obs), act);
     hb = serl_act(serl_dot7(b[i1], wb, obs), act);
   }
+  sync.start(nchunks + 1);
   sync(0, nchunks + 1);
   for (int l = 0; l <= L; ++l) {
     float pa[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -869,6 +885,7 @@ static __device__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const
     h = serl_act(acc, act);
   }
   CITW_T(22);
+  sync.start(L + 2);
   sync(0, L + 2);
   for (int l = 0; l <= L; ++l) {
     if constexpr (BC) issue(l);
@@ -962,6 +979,7 @@ static __device__ void serl_actor_forward_half32(const serl_rollout_desc &dd, co
     acc = serl_dot7(acc, w0, obs);
     h = serl_act(acc, act);
   }
+  sync.start(L + 2);
   sync(0, L + 2);
   for (int l = 0; l <= L; ++l) {
     float row[H];
@@ -1046,6 +1064,7 @@ static __device__ void serl_actor_forward_quarter32(const serl_rollout_desc &dd,
     acc = serl_dot7(acc, w0, obs);
     h[r] = serl_act(acc, act);
   }
+  sync.start(L + 2);
   sync(0, L + 2);
   for (int l = 0; l <= L; ++l) {
     float row[2][H], acc[2], gm[2], bt[2];
@@ -1092,13 +1111,15 @@ static __device__ void serl_actor_forward_quarter32(const serl_rollout_desc &dd,
 }
 
 
-template <bool BC = false, class Sync>
+// SMALL = false: without the whole-row forms of H = 32 / 64 (the team kernels' actor wavefronts: H = 32 has kernels of its own there, and
+// every variant this dispatcher carries adds hoisted address arithmetic to a wavefront that lives in 256 registers; H = 64 takes the generic pass)
+template <bool BC = false, bool SMALL = true, class Sync>
 static __device__ __forceinline__ void serl_actor_forward(const serl_rollout_desc &dd, const float *w, const float obs[7],
                                                           float act_out[3], Sync &sync, float *hx = nullptr)
 {
   const int H = __builtin_amdgcn_readfirstlane(dd.hidden);
-  if (H == 32) serl_actor_forward_small<32>(dd, w, obs, act_out, sync);
-  else if (H == 64) serl_actor_forward_small<64>(dd, w, obs, act_out, sync);
+  if (SMALL && H == 32) serl_actor_forward_small<32>(dd, w, obs, act_out, sync);
+  else if (SMALL && H == 64) serl_actor_forward_small<64>(dd, w, obs, act_out, sync);
 #ifndef SERL_NO_CHUNKED_ACTOR
 #ifndef SERL_ACTOR_CHUNK
 #define SERL_ACTOR_CHUNK 8      // (r04 session u, H = 72 / 96 one per team: 8 = 20.5 / 19.9 us per env step with 48 spilled registers in the streamed-actor kernel, 24 = 20.7 / 20.0 with 89)
