@@ -190,12 +190,17 @@ def main():
     mixed = a.workload == 'mixed'
     modes = [MIXED_MODES[(lo * ne + e) % 6] for e in range(E)] if mixed else None
 
+    pending = []      # (all-episodes-full flag, action traces) of speculative smoothness passes not yet confirmed
+
     def evaluate(wd, refd, moe_, n_members, modes_=None):
         """one population evaluation on this rank -> (rows f64 [ne, members, ROW] on the device, length_steps, fitness)"""
         if modes_ is None:
             out = eng.rollout(wd, spec, moe_, refd, t_max=80.0, traces='actions', lanes_per_wave=a.lanes, sync=False)
             ls, fit, lt, cs = out['length_steps'], out['fitness'], out['length_t'], out['cost_steps'].double()
-            sm = metrics.calc_smoothness(out['actions'], ls)                          # a11, on device
+            # a11, on device, enqueued behind the kernel as if every episode flew the whole table (an evaluation's usual case); the
+            # flag is read after the step's own host synchronisation (one_step) and the general path taken if it says otherwise
+            sm, full = metrics.calc_smoothness_speculative(out['actions'], ls)
+            pending.append((full, out['actions']))
             ls_host = None
         else:      # one launch per dynamics build, side by side on streams of their own (evaluate_pop)
             r = serl_amd.evaluate_pop(wd, mode=modes_, num_evals=ne, refs=refd, t_max=80, spec=spec, engine=eng)
@@ -211,6 +216,13 @@ def main():
         g = sd.gather_rows(rows, gather_pop, world, rank, device=dev)
         pop_fitness = g[..., 0].mean(0)
         champion = int(torch.argmax(pop_fitness))
+        while pending:      # (behind the host synchronisation above: the flags are there)
+            full, acts = pending.pop()
+            if not bool(full):      # some episode ended early: the smoothness column again by the general path, the rows rebuilt
+                pending.clear()
+                sm = metrics.calc_smoothness(acts, ls)
+                rows[..., 2] = sm.view(pop, ne).transpose(0, 1)
+                g = sd.gather_rows(rows, gather_pop, world, rank, device=dev)
         return ls, fit, g, champion
 
     def barrier():

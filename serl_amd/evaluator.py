@@ -311,11 +311,10 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
                                (refs if (whole or refs.dim() == 2) else refs[torch.as_tensor(idx)]), build=b,
                                faults=faults, err0=None if err0 is None else err0[idx],
                                tick0=None if tick0 is None else tick0[idx], t_max=t_max, sensor_noise=sn, sensor_row=sr,
-                               traces=want, transitions=transitions, lanes_per_wave=lanes_per_wave, sync=not many,
+                               traces=want, transitions=transitions, lanes_per_wave=lanes_per_wave, sync=not (many or whole),
                                concurrent_episodes=(E - len(idx)) if many else 0, env_config=env_cfg, incremental=incremental)
-        if whole:
+        if whole:      # (not waited for: the smoothness pass below is enqueued behind the kernel first)
             out = o
-            kernel_ms = engine.last_kernel_ms
             break
         if not many:
             kernel_ms += engine.last_kernel_ms
@@ -344,10 +343,17 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
             raise RuntimeError('reference table too short: %d episodes were still running after %d steps'
                                % (int((out['length_steps'] < 0).sum()), T_ref))
     engine.last_kernel_ms = kernel_ms
+    spec_sm = None
+    if need_actions:      # enqueued before the first host round trip, as if every episode flew the whole table (the usual case)
+        spec_sm = metrics.calc_smoothness_speculative(out['actions'], out['length_steps'])
     ret = out['fitness'].cpu().numpy()
     ls = out['length_steps'].cpu().numpy()
+    if not parts:      # one launch for the whole population: its time and its sanity check now that the host has waited
+        engine.last_kernel_ms = engine.kernel_ms()
+        if (ls < 0).any():
+            raise RuntimeError('reference table too short: %d episodes were still running after %d steps' % (int((ls < 0).sum()), T_ref))
     if need_actions:
-        sm = metrics.calc_smoothness(out['actions'], ls).cpu().numpy()
+        sm = (spec_sm[0] if bool(spec_sm[1]) else metrics.calc_smoothness(out['actions'], ls)).cpu().numpy()
     else:
         sm = np.zeros(E)
     fit = ret + sm if smooth_fitness else ret.copy()
