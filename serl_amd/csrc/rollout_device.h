@@ -184,6 +184,10 @@ struct SerlBarrierCredit {
   bool defer_last = false;      // the last piece pays nothing: the caller hands its result on first and pays the rest with (0, 1)
   int inc = 0;                  // per_step / n in 16.16 fixed point: a forward pass divides once (start), not per piece (the chunked passes have 37)
   __device__ __forceinline__ void start(int n) { inc = (per_step << 16) / n; }      // every forward pass calls it in front of its first piece
+  __device__ __forceinline__ void upto(int target)      // the caller's own instalment (the actor wavefront's first barriers of a step, in front of its books)
+  {
+    while (done < target) { SERL_CREDIT_JIT(*this); __builtin_amdgcn_s_barrier(); ++done; }
+  }
   __device__ __forceinline__ void operator()(int piece, int n)
   {
     if (defer_last && piece + 1 == n) return;
