@@ -199,8 +199,12 @@ def main():
             ls, fit, lt, cs = out['length_steps'], out['fitness'], out['length_t'], out['cost_steps'].double()
             # a11, on device, enqueued behind the kernel as if every episode flew the whole table (an evaluation's usual case); the
             # flag is read after the step's own host synchronisation (one_step) and the general path taken if it says otherwise
-            sm, full = metrics.calc_smoothness_speculative(out['actions'], ls)
-            pending.append((full, out['actions']))
+            guess = metrics.calc_smoothness_speculative(out['actions'], ls)      # (None: the last evaluation of this shape had early endings)
+            if guess is None:
+                sm = metrics.calc_smoothness(out['actions'], ls)
+            else:
+                sm = guess[0]
+                pending.append((guess[1], out['actions']))
             ls_host = None
         else:      # one launch per dynamics build, side by side on streams of their own (evaluate_pop)
             r = serl_amd.evaluate_pop(wd, mode=modes_, num_evals=ne, refs=refd, t_max=80, spec=spec, engine=eng)
@@ -218,7 +222,7 @@ def main():
         champion = int(torch.argmax(pop_fitness))
         while pending:      # (behind the host synchronisation above: the flags are there)
             full, acts = pending.pop()
-            if not bool(full):      # some episode ended early: the smoothness column again by the general path, the rows rebuilt
+            if not metrics.smoothness_speculation_result(acts, full):      # some episode ended early: the smoothness column again by the general path, the rows rebuilt
                 pending.clear()
                 sm = metrics.calc_smoothness(acts, ls)
                 rows[..., 2] = sm.view(pop, ne).transpose(0, 1)

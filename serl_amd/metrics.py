@@ -72,13 +72,31 @@ def _smoothness_full(y, N, dt):
 def calc_smoothness_speculative(actions, length_steps, dt=0.01):
     """The evaluation's usual case without a host round trip: calc_smoothness as if every episode had flown the whole table, enqueued
     on the current stream right behind the rollout kernel (nothing waits for `length_steps` on the host), plus a device flag that
-    says whether that was true.  Returns (smoothness f64 [E], all_full bool scalar on the device); when the flag reads False --
-    after the caller's own synchronisation -- the caller calls calc_smoothness(actions, length_steps) instead."""
+    says whether that was true.  Returns (smoothness f64 [E], all_full bool scalar on the device), or None when the last batch of this
+    shape was a miss (smoothness_speculation_result); when the flag reads False -- after the caller's own synchronisation -- the caller
+    calls calc_smoothness(actions, length_steps) instead."""
     E, T, A = actions.shape
+    if (E, T) in _SPEC_MISS:      # a batch of this shape had early endings last time (untrained / perturbed actors): the guess would be paid twice
+        return None
     all_full = (length_steps.abs() == T).all()
     if T < 4:
         return torch.zeros(E, dtype=torch.float64, device=actions.device), all_full
     return _smoothness_full(actions, T, dt), all_full
+
+
+_SPEC_MISS = set()
+
+
+def smoothness_speculation_result(actions, all_full):
+    """What the caller found when it read the flag of calc_smoothness_speculative (after its own synchronisation): remembers a miss so that the
+    next batch of the same shape goes straight to the general path, forgets it after a hit.  Returns the flag as a bool."""
+    ok = bool(all_full)
+    E, T, _ = actions.shape
+    if ok:
+        _SPEC_MISS.discard((E, T))
+    else:
+        _SPEC_MISS.add((E, T))
+    return ok
 
 
 def _smoothness_dft(actions, lengths, dt):
