@@ -7,12 +7,19 @@
 #endif
 #define CITW_OUT2_ROWS 1
 #define CITW_INV_SLOTS 8
-// Which role of the partitioned evaluation runs on which hardware wavefront (w and w + 4 share a SIMD), and a static issue priority
-// (round 4, sweeps k / l after the short libm and the new balance, 150 episodes, us per env step: identity 16.85 - 16.89; roles 1 and 6
-// exchanged -- role 1, last at B1, beside role 2, which waits longest there; role 5 beside role 6 -- 16.60; + role 1 at priority 1:
-// 16.56 - 16.61).  One episode per team only: the lane-group kernels keep the identity.
+// Which role of the partitioned evaluation runs on which hardware wavefront (w and w + 4 share a SIMD, the actor is wavefront 7), and a static
+// issue priority.  Round 4, sweeps k / l (after the short libm and the new balance, 150 episodes, us per env step): identity 16.85 - 16.89;
+// roles 1 and 6 exchanged -- role 1, last at B1, beside role 2, which waits longest there; role 5 beside role 6 -- 16.60; + role 1 at
+// priority 1: 16.56 - 16.61.  Session ae (books on the actor wavefront, its forward pass a quarter shorter): all 105 pairings of the seven
+// roles on the four SIMDs (tools/sweep_roles.py, profiles/r04_ae_roles.json: 15.80 - 18.40): the look-up role 0 beside the LDS-resident
+// actor, (1, 2) (3, 4) (5, 6) on the others: 15.80 - 15.83 against 15.89 - 15.97 of the map below it.  Beside an actor that STREAMS its
+// weights (SERL10, the TD3 actor: busy most of the step, at priority) the older map stays -- 17.55 against 17.8 with the new one (session af).
+// One episode per team only: the lane-group kernels keep the identity.
 #ifndef SERL_TEAM_ROLES
-#define SERL_TEAM_ROLES {0, 6, 2, 3, 4, 5, 1, 7, 8, 9, 10, 11, 12, 13, 14, 15}
+#define SERL_TEAM_ROLES {1, 3, 5, 0, 2, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}
+#endif
+#ifndef SERL_TEAMS_ROLES
+#define SERL_TEAMS_ROLES {0, 6, 2, 3, 4, 5, 1, 7, 8, 9, 10, 11, 12, 13, 14, 15}
 #endif
 #ifndef CITW_ROLE_PRIO_MASK
 #define CITW_ROLE_PRIO_MASK 0x02
