@@ -83,6 +83,55 @@ def test_metrics_against_reference_numbers(golden):
     assert abs(metrics.calc_nMAE(err) - want) < 1e-12
 
 
+def test_smoothness_full_pass_and_speculation():
+    """The lean full-length pass (weighted 2-norm of the half spectrum) against the oracle's numpy restatement of base/core/utils.py:82-120,
+    and the speculative variant: a hit returns the same numbers and a true flag, a miss is remembered per batch shape and forgotten after a hit."""
+    from serl_amd import metrics
+    from oracle.smoothness import calc_smoothness as ref_smoothness
+    rng = np.random.default_rng(3)
+    for N in (8001, 2001, 800, 57):
+        a = (rng.normal(size=(3, N, 3)).cumsum(1) * 0.01)
+        got = metrics.calc_smoothness(torch.from_numpy(a)).numpy()
+        want = np.array([ref_smoothness(a[e]) for e in range(3)])
+        np.testing.assert_allclose(got, want, rtol=1e-10)
+    metrics._SPEC_MISS.clear()
+    a = torch.from_numpy(rng.normal(size=(4, 301, 3)).cumsum(1) * 0.01)
+    full = torch.full((4,), 301, dtype=torch.int32)
+    sm, flag = metrics.calc_smoothness_speculative(a, full)
+    assert metrics.smoothness_speculation_result(a, flag)
+    np.testing.assert_allclose(sm.numpy(), metrics.calc_smoothness(a, full).numpy(), rtol=1e-13)
+    short = torch.tensor([301, 120, 301, -301], dtype=torch.int32)      # (a negative length: the table ran out -- still the whole table)
+    sm, flag = metrics.calc_smoothness_speculative(a, short)
+    assert not metrics.smoothness_speculation_result(a, flag)            # the caller takes the general path ...
+    assert metrics.calc_smoothness_speculative(a, full) is None          # ... and the next batch of this shape does not guess
+    want = np.array([ref_smoothness(a[e, :n].numpy()) for e, n in enumerate([301, 120, 301, 301])])
+    np.testing.assert_allclose(metrics.calc_smoothness(a, short).numpy(), want, rtol=1e-10)
+    metrics._SPEC_MISS.clear()
+
+
+def test_role_maps_and_pairing_sweep():
+    """The role <-> wavefront maps of the team kernels are permutations of the seven roles with the actor on wavefront 7, and
+    tools/sweep_roles.py enumerates every pairing of the roles on the four SIMDs exactly once (105), the shipped map first."""
+    import re, subprocess, sys, glob
+    for f in glob.glob(os.path.join(ROOT, 'serl_amd', 'csrc', 'rollout_team_*.hip')):
+        t = open(f).read()
+        for name in ('SERL_TEAM_ROLES', 'SERL_TEAMS_ROLES'):
+            m = re.search(r'#define %s \{([0-9, ]+)\}' % name, t)
+            if m is None:
+                continue
+            r = [int(v) for v in m.group(1).split(',')]
+            assert len(r) == 16 and sorted(r[:7]) == list(range(7)) and r[7] == 7, (f, name, r)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'sweep_roles.py')], capture_output=True, text=True, check=True).stdout.split()
+    assert len(out) == 105 and len(set(out)) == 105
+    pair_sets = set()
+    for m in out:
+        v = int(m, 16)
+        w = [(v >> (4 * i)) & 15 for i in range(8)]
+        assert sorted(w) == list(range(8)) and w[7] == 7
+        pair_sets.add(frozenset(frozenset((w[i], w[i + 4])) for i in range(4)))
+    assert len(pair_sets) == 105
+
+
 def test_reference_tables_and_mode_names(golden):
     from serl_amd import refsignals, builds
     ref = refsignals.tabulate(*refsignals.base_reference(80), 80)
