@@ -207,7 +207,9 @@ int serl_ctx_load_build(serl_ctx *ctx, int slot, const serl_build_desc *build);
  *   SERL_PROFILE=1                           cycle counters for serl_debug_profile
  *   SERL_SPLIT_ACTOR=1                       one-episode teams with a streamed actor (hidden > 64): two actor wavefronts share the forward pass
  *   SERL_JITTER_SEED=n, SERL_JITTER_SITES=m  acted on only by the TEST-ONLY stress build of the team kernels (libserl_amd_jitter.so:
- *                                            poisoned LDS blackboards, seeded pauses around every hand-over; the product ignores them) */
+ *                                            poisoned LDS blackboards, seeded pauses around every hand-over; the product ignores them;
+ *                                            a development build -DSERL_DEV_ROLE_MAP=1 reads SERL_JITTER_SITES as the role <-> wavefront map of
+ *                                            the one-episode team kernels, a nibble per hardware wavefront: tools/sweep_roles.py) */
 
 /* One population evaluation: all episodes of the descriptor, one fused kernel launch per call. */
 int serl_rollout(serl_ctx *ctx, const serl_rollout_desc *desc, void *stream);
