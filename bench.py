@@ -198,7 +198,7 @@ def main():
             out = eng.rollout(wd, spec, moe_, refd, t_max=80.0, traces='actions', lanes_per_wave=a.lanes, sync=False)
             ls, fit, lt, cs = out['length_steps'], out['fitness'], out['length_t'], out['cost_steps'].double()
             # a11, on device, enqueued behind the kernel as if every episode flew the whole table (an evaluation's usual case); the
-            # flag is read after the step's own host synchronisation (one_step) and the general path taken if it says otherwise
+            # flag is read in one_step, in front of the all-gather, and the general path taken if it says otherwise
             guess = metrics.calc_smoothness_speculative(out['actions'], ls)      # (None: the last evaluation of this shape had early endings)
             if guess is None:
                 sm = metrics.calc_smoothness(out['actions'], ls)
@@ -217,16 +217,17 @@ def main():
     def one_step():
         """one population evaluation on this rank + the fitness all-gather + index selection"""
         rows, ls, fit = evaluate(w, ref, moe, pop, modes)
-        g = sd.gather_rows(rows, gather_pop, world, rank, device=dev)
-        pop_fitness = g[..., 0].mean(0)
-        champion = int(torch.argmax(pop_fitness))
-        while pending:      # (behind the host synchronisation above: the flags are there)
+        # the guess is confirmed (or replaced) BEFORE the all-gather: every rank makes exactly one collective call per step whatever its
+        # own episodes did (reading the flag waits for this rank's kernel and smoothness pass -- the step's host synchronisation, moved up)
+        while pending:
             full, acts = pending.pop()
-            if not metrics.smoothness_speculation_result(acts, full):      # some episode ended early: the smoothness column again by the general path, the rows rebuilt
+            if not metrics.smoothness_speculation_result(acts, full):      # some episode ended early: the smoothness column by the general path
                 pending.clear()
                 sm = metrics.calc_smoothness(acts, ls)
                 rows[..., 2] = sm.view(pop, ne).transpose(0, 1)
-                g = sd.gather_rows(rows, gather_pop, world, rank, device=dev)
+        g = sd.gather_rows(rows, gather_pop, world, rank, device=dev)
+        pop_fitness = g[..., 0].mean(0)
+        champion = int(torch.argmax(pop_fitness))
         return ls, fit, g, champion
 
     def barrier():
