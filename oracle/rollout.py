@@ -66,6 +66,17 @@ def make_build_desc(build):
     return bd
 
 
+def activation(act, x):
+    """The actor's activation (include/serl_amd.h: det_tanhf / det_expm1f_neg / LeakyReLU) of the C restatement on an f32 array"""
+    L = _dyn.lib()
+    L.serl_oracle_act.argtypes = [ctypes.c_int, _F, ctypes.c_int, _F]
+    L.serl_oracle_act.restype = None
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty_like(x)
+    L.serl_oracle_act(ACT[act] if isinstance(act, str) else int(act), x.ctypes.data_as(_F), len(x), y.ctypes.data_as(_F))
+    return y
+
+
 def rollout(weights, net, member_of_episode, ref, *, build='h2000_v90', faults=None, err0=None,
             tick0=None, action_noise=None, noise_row=None, sensor_noise=None, sensor_row=None, t_max=80.0, traces=False, transitions=False, threads=1,
             env_config=0, incremental=False):

@@ -135,6 +135,12 @@ static float act_f(float v, int act)
   }
 }
 
+/* the actor's activation on an array (unit check of the device's det_tanhf / det_expm1f_neg against this restatement, bit for bit) */
+void serl_oracle_act(int act, const float *x, int n, float *y)
+{
+  for (int i = 0; i < n; ++i) y[i] = act_f(x[i], act);
+}
+
 /* Actor forward, f32 (genetic_agent.py:69-109).  hbuf: 3*H scratch floats. */
 /* The f32 arithmetic of the actor as include/serl_amd.h specifies it (shared with the HIP kernels, bit for bit):
  *   dot product   four interleaved partial sums p[j & 3] = fmaf(w[j], h[j], p[j & 3]) over ascending j (exact products,

@@ -61,6 +61,7 @@ def lib():
                                                ctypes.c_int, VP]
         L.serl_xcheck_div_const.argtypes = [VP, ctypes.c_int, ctypes.c_double, ctypes.c_double, VP, VP, VP]
         L.serl_xcheck_libm.argtypes = [ctypes.c_int, VP, ctypes.c_int, ctypes.c_double, VP, VP, VP]
+        L.serl_xcheck_act.argtypes = [ctypes.c_int, VP, ctypes.c_int, VP, VP]
         _lib = L
     return _lib
 
@@ -85,6 +86,17 @@ def libm(kind, x, c=0.0):
     assert rc_ == 0
     torch.cuda.synchronize()
     return o0.cpu().numpy(), o1.cpu().numpy()
+
+
+def activation(act, x):
+    """serl_act (0 tanh / 1 ELU / 2 LeakyReLU) of serl_amd/csrc/rollout_device.h on the GPU, f32 array in, f32 array out"""
+    import numpy as np, torch
+    xt = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).cuda().contiguous()
+    y = torch.empty_like(xt)
+    rc_ = lib().serl_xcheck_act(int(act), xt.data_ptr(), xt.numel(), y.data_ptr(), None)
+    assert rc_ == 0
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
 
 
 def rollout(weights, spec, member_of_episode, ref, *, build='h2000_v90', t_max=80.0, lanes_per_wave=8):

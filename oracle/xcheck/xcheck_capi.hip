@@ -39,6 +39,13 @@ __global__ void xcheck_libm_kernel(int kind, const double *x, int n, double c, d
   else o0[i] = citw_pow(x[i], c);
 }
 
+// the actor's activation of the product (rollout_device.h: serl_act -> det_tanhf / det_expm1f_neg / LeakyReLU) on an f32 array
+__global__ void xcheck_act_kernel(int act, const float *x, int n, float *y)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = serl_act(x[i], act);
+}
+
 static void xcheck_args(RolloutArgs &a, const double *blob, int n_ro, double dt, int lanes, int waves, int *grid)
 {
   a.ro = blob; a.t3 = blob + n_ro; a.x0 = a.t3 + 46; a.dw0 = a.x0 + 19;
@@ -105,6 +112,12 @@ int serl_xcheck_div_const(const double *x, int n, double c, double rc, double *f
 int serl_xcheck_libm(int kind, const double *x, int n, double c, double *o0, double *o1, void *stream)
 {
   hipLaunchKernelGGL(xcheck_libm_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, kind, x, n, c, o0, o1);
+  return hipGetLastError() == hipSuccess ? SERL_OK : SERL_E_HIP;
+}
+
+int serl_xcheck_act(int act, const float *x, int n, float *y, void *stream)
+{
+  hipLaunchKernelGGL(xcheck_act_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, act, x, n, y);
   return hipGetLastError() == hipSuccess ? SERL_OK : SERL_E_HIP;
 }
 
