@@ -4,6 +4,7 @@ best dozen twice more; the product library before and after.  Writes gpurun_out/
 import json, os, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else 'roles'
+EPISODES = sys.argv[2] if len(sys.argv) > 2 else '150'      # 150: one episode per team; 384 / 1023: the lane-group kernels (build them with -DSERL_DEV_ROLE_MAP=1 too)
 O = os.path.join(R, 'gpurun_out', tag)
 os.makedirs(O, exist_ok=True)
 maps = subprocess.run([sys.executable, os.path.join(R, 'tools', 'sweep_roles.py')], capture_output=True, text=True).stdout.split()
@@ -13,9 +14,9 @@ def run(lib, m=None):
     env = dict(os.environ, SERL_LIB=os.path.join(R, 'serl_amd', 'csrc', lib))
     if m is not None:
         env['SERL_JITTER_SITES'] = '0x' + m
-    r = subprocess.run([sys.executable, os.path.join(R, 'tools', 'ab.py'), '150'], capture_output=True, text=True, env=env, cwd=R, timeout=120)
+    r = subprocess.run([sys.executable, os.path.join(R, 'tools', 'ab.py'), EPISODES], capture_output=True, text=True, env=env, cwd=R, timeout=120)
     try:
-        return json.loads(r.stdout.strip().splitlines()[-1].split(' ', 1)[1])['loop_E150']
+        return json.loads(r.stdout.strip().splitlines()[-1].split(' ', 1)[1])['loop_E' + EPISODES]
     except Exception:
         return None
 
