@@ -3,16 +3,18 @@ import os, subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, '_build', 'libcitation_oracle.so')
+LIB_SHORT = os.path.join(HERE, '_build', 'libcitation_oracle_shortlibm.so')      # sin / cos / tan / pow = the CPU build of the product's citation_libm.h (citation_rt.h)
 
 
-def build(force=False):
+def build(force=False, short_libm=False):
+    """Both flavours are built together; returns the glibc one (pinned to the reference binary) or, short_libm=True, the one that
+    shares its sin / cos / tan / pow with the kernels (GPU-vs-oracle comparisons at zero tolerance)."""
     srcs = [os.path.join(HERE, f) for f in ('citation_ref.c', 'rollout_ref.c', 'citation_rt.h', 'citation_step.h',
-                                            '../include/serl_amd.h')]
+                                            '../include/serl_amd.h', '../serl_amd/csrc/citation_libm.h', 'Makefile')]
     srcs += [os.path.join(HERE, 'gen', f) for f in sorted(os.listdir(os.path.join(HERE, 'gen')))]
-    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
-        return LIB
-    subprocess.run(['make', '-C', HERE, '-s'], check=True)
-    return LIB
+    if force or not all(os.path.exists(l) and all(os.path.getmtime(l) >= os.path.getmtime(s) for s in srcs) for l in (LIB, LIB_SHORT)):
+        subprocess.run(['make', '-C', HERE, '-s'] + (['-B'] if force else []), check=True)
+    return LIB_SHORT if short_libm else LIB
 
 
 REF_ARCHIVE = os.path.join(HERE, '_ref', 'reference_path.zip')

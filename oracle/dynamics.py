@@ -11,13 +11,13 @@ from . import build as _build
 _D = ctypes.POINTER(ctypes.c_double)
 DATA_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'serl_amd', 'data')
 CODE_IDS = {'nominal': 0, 'ice': 1, 'cg_timed': 2, 'gust': 3, 'test': 4}
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        L = ctypes.CDLL(_build.build())
+def lib(short_libm=False):
+    """short_libm: the flavour whose sin / cos / tan / pow are the product's short bodies compiled for the CPU (oracle/citation_rt.h)"""
+    if short_libm not in _libs:
+        L = ctypes.CDLL(_build.build(short_libm=bool(short_libm)))
         L.cit_instance_size.restype = ctypes.c_int
         L.cit_reset.argtypes = [ctypes.c_void_p, ctypes.c_int, _D, _D, _D, _D, ctypes.c_double]
         L.cit_reset.restype = None
@@ -28,8 +28,8 @@ def lib():
         for f in ('cit_B', 'cit_X', 'cit_DW'):
             getattr(L, f).argtypes = [ctypes.c_void_p]
             getattr(L, f).restype = _D
-        _lib = L
-    return _lib
+        _libs[short_libm] = L
+    return _libs[short_libm]
 
 
 _index = None
@@ -57,8 +57,8 @@ def load_build_data(build):
 class CitationDynamics:
     """One independent simulator instance (the reference allows one per loaded library image)."""
 
-    def __init__(self, build='h2000_v90'):
-        self.L = lib()
+    def __init__(self, build='h2000_v90', short_libm=False):
+        self.L = lib(short_libm)
         self.data, self.ent = load_build_data(build)
         self.code = CODE_IDS[self.ent['code']]
         self.buf = ctypes.create_string_buffer(self.L.cit_instance_size())

@@ -79,14 +79,14 @@ def activation(act, x):
 
 def rollout(weights, net, member_of_episode, ref, *, build='h2000_v90', faults=None, err0=None,
             tick0=None, action_noise=None, noise_row=None, sensor_noise=None, sensor_row=None, t_max=80.0, traces=False, transitions=False, threads=1,
-            env_config=0, incremental=False):
-    """Run episodes on the CPU oracle.
+            env_config=0, incremental=False, short_libm=False):
+    """Run episodes on the CPU oracle (short_libm: the flavour that shares sin / cos / tan / pow with the kernels -- oracle/citation_rt.h).
 
     weights [n_members, P] f32 (packed state_dict order); net = dict(state_dim, action_dim, hidden,
     num_layers, activation); ref [n_ep, T, 3] or [T, 3] f64 radians; faults: list of fault names or
     [n_ep, 8] rows; env_config 0 / 1 / 2 = attitude / symmetric / full, incremental = rate control
     (envs/phlabenv.py:84-97,174-176).  Returns dict of numpy arrays."""
-    L = _dyn.lib()
+    L = _dyn.lib(short_libm)
     L.serl_oracle_rollout.argtypes = [ctypes.POINTER(BuildDesc), ctypes.POINTER(RolloutDesc), ctypes.c_int]
     L.serl_oracle_rollout.restype = ctypes.c_int
     weights = np.ascontiguousarray(weights, dtype=np.float32)

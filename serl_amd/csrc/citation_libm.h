@@ -25,7 +25,9 @@
 // on its own).  __host__ __device__: tests/test_libm.py compiles the same text for the CPU.
 #pragma once
 #ifndef __HIPCC__
+#ifndef _GNU_SOURCE
 #define _GNU_SOURCE 1
+#endif
 #include <math.h>
 #endif
 #ifndef CITW_LIBM_FN
@@ -34,6 +36,21 @@
 #else
 #define CITW_LIBM_FN static inline
 #endif
+#endif
+
+// The coefficients as registers (round 5, team kernels; citation_wave.h "f64 literals ... in registers"): CITW_LK(i, literal) is slot
+// KB + i of the caller's register set when it passed one (HAVE_K, a compile-time fact after inlining; KB = where this function's
+// block starts in the role's set, chosen by tools/dag/codegen_team.py, which reads the blocks off this text) and the literal itself
+// otherwise -- in the CPU build always.  Slots count from 0 per function: citw_sincos 0 .. 14, citw_pow 0 .. 23.
+#ifdef __HIPCC__
+#include "serl_kregs.h"
+#define CITW_LIBM_KPARAMS , const bool HAVE_K = false, const CitwKRegs &KR = citw_no_kregs, const int KB = 0
+#define CITW_LIBM_KARGS , HAVE_K, KR, KB
+#define CITW_LK(i, lit) (HAVE_K ? KR.k[KB + (i)] : (lit))
+#else
+#define CITW_LIBM_KPARAMS
+#define CITW_LIBM_KARGS
+#define CITW_LK(i, lit) (lit)
 #endif
 
 CITW_LIBM_FN double citw_libm_hi_xor(double v, unsigned bits)
@@ -45,7 +62,7 @@ CITW_LIBM_FN double citw_libm_hi_xor(double v, unsigned bits)
 }
 
 // sin and cos of x
-CITW_LIBM_FN void citw_sincos(const double x, double *s, double *c)
+CITW_LIBM_FN void citw_sincos(const double x, double *s, double *c CITW_LIBM_KPARAMS)
 {
 #ifndef CITW_LIBM_NO_FALLBACK               // (tools/isa/role_isa.py counts the instructions of the short bodies without the cold paths)
   if (!(__builtin_fabs(x) < 1.0e5)) {      // huge, inf, NaN: the general-purpose body (beyond 1e5 the two-part pi/2 loses accuracy gradually)
@@ -53,12 +70,12 @@ CITW_LIBM_FN void citw_sincos(const double x, double *s, double *c)
     return;
   }
 #endif
-  const double TWO_OVER_PI = 0x1.45f306dc9c883p-1;                                   // 2/pi
-  const double PIO2_HI = 0x1.921fb54442d18p+0, PIO2_LO = 0x1.1a62633145c07p-54;      // pi/2 = HI + LO (+ 3e-33)
-  const double S1 = -0x1.5555555555549p-3, S2 = 0x1.111111110f8a6p-7, S3 = -0x1.a01a019c161d5p-13,
-               S4 = 0x1.71de357b1fe7dp-19, S5 = -0x1.ae5e68a2b9cebp-26, S6 = 0x1.5d93a5acfd57cp-33;
-  const double C1 = 0x1.555555555554cp-5, C2 = -0x1.6c16c16c15177p-10, C3 = 0x1.a01a019cb159p-16,
-               C4 = -0x1.27e4f809c52adp-22, C5 = 0x1.1ee9ebdb4b1c4p-29, C6 = -0x1.8fae9be8838d4p-37;
+  const double TWO_OVER_PI = CITW_LK(0, 0x1.45f306dc9c883p-1);                                   // 2/pi
+  const double PIO2_HI = CITW_LK(1, 0x1.921fb54442d18p+0), PIO2_LO = CITW_LK(2, 0x1.1a62633145c07p-54);      // pi/2 = HI + LO (+ 3e-33)
+  const double S1 = CITW_LK(3, -0x1.5555555555549p-3), S2 = CITW_LK(4, 0x1.111111110f8a6p-7), S3 = CITW_LK(5, -0x1.a01a019c161d5p-13),
+               S4 = CITW_LK(6, 0x1.71de357b1fe7dp-19), S5 = CITW_LK(7, -0x1.ae5e68a2b9cebp-26), S6 = CITW_LK(8, 0x1.5d93a5acfd57cp-33);
+  const double C1 = CITW_LK(9, 0x1.555555555554cp-5), C2 = CITW_LK(10, -0x1.6c16c16c15177p-10), C3 = CITW_LK(11, 0x1.a01a019cb159p-16),
+               C4 = CITW_LK(12, -0x1.27e4f809c52adp-22), C5 = CITW_LK(13, 0x1.1ee9ebdb4b1c4p-29), C6 = CITW_LK(14, -0x1.8fae9be8838d4p-37);
   const double kd = __builtin_rint(x * TWO_OVER_PI);
   double r = __builtin_fma(-kd, PIO2_HI, x);           // exact: |r| < 1 is a multiple of ulp(x) or of 2^-52
   r = __builtin_fma(-kd, PIO2_LO, r);
@@ -86,24 +103,24 @@ CITW_LIBM_FN void citw_sincos(const double x, double *s, double *c)
   *c = citw_libm_hi_xor(c0, (((unsigned)n + 1u) & 2u) << 30);
 }
 
-CITW_LIBM_FN double citw_sin(const double x) { double s, c; citw_sincos(x, &s, &c); return s; }
-CITW_LIBM_FN double citw_cos(const double x) { double s, c; citw_sincos(x, &s, &c); return c; }
+CITW_LIBM_FN double citw_sin(const double x CITW_LIBM_KPARAMS) { double s, c; citw_sincos(x, &s, &c CITW_LIBM_KARGS); return s; }
+CITW_LIBM_FN double citw_cos(const double x CITW_LIBM_KPARAMS) { double s, c; citw_sincos(x, &s, &c CITW_LIBM_KARGS); return c; }
 
-CITW_LIBM_FN double citw_tan(const double x)
+CITW_LIBM_FN double citw_tan(const double x CITW_LIBM_KPARAMS)
 {
   double s, c;
-  citw_sincos(x, &s, &c);
+  citw_sincos(x, &s, &c CITW_LIBM_KARGS);
   return s / c;
 }
 
 // x^c: the short body for a base in [0.71, 1.41] and |c| <= 16 (the model's one call: a temperature ratio to the power 4.256), the
 // general-purpose one for anything else
-CITW_LIBM_FN double citw_pow(const double x, const double c)
+CITW_LIBM_FN double citw_pow(const double x, const double c CITW_LIBM_KPARAMS)
 {
 #ifndef CITW_LIBM_NO_FALLBACK
   if (!(x >= 0.71 && x <= 1.41 && __builtin_fabs(c) <= 16.0)) return pow(x, c);
 #endif
-  const double LN2_HI = 0x1.62e42fefa39efp-1, LN2_LO = 0x1.abc9e3b39803fp-56, INV_LN2 = 0x1.71547652b82fep+0;
+  const double LN2_HI = CITW_LK(0, 0x1.62e42fefa39efp-1), LN2_LO = CITW_LK(1, 0x1.abc9e3b39803fp-56), INV_LN2 = CITW_LK(2, 0x1.71547652b82fep+0);
   // ln x = 2 q + q z (2/3 + z (2/5 + ... )), q = f / (2 + f), f = x - 1 (exact for x in [1/2, 2])
   const double f = x - 1.0, d = 2.0 + f;
   const double q = f / d;
@@ -111,15 +128,15 @@ CITW_LIBM_FN double citw_pow(const double x, const double c)
   const double d_lo = (2.0 - d) + f;                                   // d + d_lo = 2 + f exactly
   const double qc = q_lo - q * (d_lo / d);                              // the quotient's tail with the divisor's rounding error taken out
   const double z = q * q;
-  double p = __builtin_fma(z, 0x1.8618618618618p-4, 0x1.af286bca1af28p-4);     // 2/21, 2/19
-  p = __builtin_fma(z, p, 0x1.e1e1e1e1e1e1ep-4);                        // 2/17
-  p = __builtin_fma(z, p, 0x1.1111111111111p-3);                        // 2/15
-  p = __builtin_fma(z, p, 0x1.3b13b13b13b14p-3);                        // 2/13
-  p = __builtin_fma(z, p, 0x1.745d1745d1746p-3);                        // 2/11
-  p = __builtin_fma(z, p, 0x1.c71c71c71c71cp-3);                        // 2/9
-  p = __builtin_fma(z, p, 0x1.2492492492492p-2);                        // 2/7
-  p = __builtin_fma(z, p, 0x1.999999999999ap-2);                        // 2/5
-  p = __builtin_fma(z, p, 0x1.5555555555555p-1);                        // 2/3
+  double p = __builtin_fma(z, CITW_LK(3, 0x1.8618618618618p-4), CITW_LK(4, 0x1.af286bca1af28p-4));     // 2/21, 2/19
+  p = __builtin_fma(z, p, CITW_LK(5, 0x1.e1e1e1e1e1e1ep-4));                        // 2/17
+  p = __builtin_fma(z, p, CITW_LK(6, 0x1.1111111111111p-3));                        // 2/15
+  p = __builtin_fma(z, p, CITW_LK(7, 0x1.3b13b13b13b14p-3));                        // 2/13
+  p = __builtin_fma(z, p, CITW_LK(8, 0x1.745d1745d1746p-3));                        // 2/11
+  p = __builtin_fma(z, p, CITW_LK(9, 0x1.c71c71c71c71cp-3));                        // 2/9
+  p = __builtin_fma(z, p, CITW_LK(10, 0x1.2492492492492p-2));                        // 2/7
+  p = __builtin_fma(z, p, CITW_LK(11, 0x1.999999999999ap-2));                        // 2/5
+  p = __builtin_fma(z, p, CITW_LK(12, 0x1.5555555555555p-1));                        // 2/3
   const double ln_hi = 2.0 * q;                                         // exact
   const double ln_lo = __builtin_fma(q * z, p, 2.0 * qc);
   // y = c ln x as head + tail
@@ -129,16 +146,16 @@ CITW_LIBM_FN double citw_pow(const double x, const double c)
   const double kd = __builtin_rint(yh * INV_LN2);
   double r = __builtin_fma(-kd, LN2_HI, yh);
   r = __builtin_fma(-kd, LN2_LO, r) + yl;
-  double e = __builtin_fma(r, 0x1.6124613a86d09p-33, 0x1.1eed8eff8d898p-29);   // 1/13!, 1/12!
-  e = __builtin_fma(r, e, 0x1.ae64567f544e4p-26);                       // 1/11!
-  e = __builtin_fma(r, e, 0x1.27e4fb7789f5cp-22);                       // 1/10!
-  e = __builtin_fma(r, e, 0x1.71de3a556c734p-19);                       // 1/9!
-  e = __builtin_fma(r, e, 0x1.a01a01a01a01ap-16);                       // 1/8!
-  e = __builtin_fma(r, e, 0x1.a01a01a01a01ap-13);                       // 1/7!
-  e = __builtin_fma(r, e, 0x1.6c16c16c16c17p-10);                       // 1/6!
-  e = __builtin_fma(r, e, 0x1.1111111111111p-7);                        // 1/5!
-  e = __builtin_fma(r, e, 0x1.5555555555555p-5);                        // 1/4!
-  e = __builtin_fma(r, e, 0x1.5555555555555p-3);                        // 1/3!
+  double e = __builtin_fma(r, CITW_LK(13, 0x1.6124613a86d09p-33), CITW_LK(14, 0x1.1eed8eff8d898p-29));   // 1/13!, 1/12!
+  e = __builtin_fma(r, e, CITW_LK(15, 0x1.ae64567f544e4p-26));                       // 1/11!
+  e = __builtin_fma(r, e, CITW_LK(16, 0x1.27e4fb7789f5cp-22));                       // 1/10!
+  e = __builtin_fma(r, e, CITW_LK(17, 0x1.71de3a556c734p-19));                       // 1/9!
+  e = __builtin_fma(r, e, CITW_LK(18, 0x1.a01a01a01a01ap-16));                       // 1/8!
+  e = __builtin_fma(r, e, CITW_LK(19, 0x1.a01a01a01a01ap-13));                       // 1/7!
+  e = __builtin_fma(r, e, CITW_LK(20, 0x1.6c16c16c16c17p-10));                       // 1/6!
+  e = __builtin_fma(r, e, CITW_LK(21, 0x1.1111111111111p-7));                        // 1/5!
+  e = __builtin_fma(r, e, CITW_LK(22, 0x1.5555555555555p-5));                        // 1/4!
+  e = __builtin_fma(r, e, CITW_LK(23, 0x1.5555555555555p-3));                        // 1/3!
   e = __builtin_fma(r, e, 0.5);
   const double em1 = __builtin_fma(r * r, e, r);                        // exp(r) - 1
   return __builtin_ldexp(1.0 + em1, (int)kd);

@@ -251,6 +251,17 @@ __shared__ alignas(64) unsigned g_pflag[16];     // ... and for the values of th
 __shared__ alignas(64) double g_y[32 * CITW_GROUPS];   // team kernels: values that cross between the wavefronts BEHIND barrier B1 (task graph)
 #endif
 
+// ---- f64 literals of the generated team code in registers (round 5; tools/dag/codegen_team.py assign_kregs).  An f64 literal with a
+// non-zero low dword costs two 32-bit moves at every use (the build keeps the machine LICM from hoisting them: as SGPR pairs they
+// spilled) -- 15 % of the headline kernel's static instructions.  A wavefront's role is fixed for the episode, so it loads the
+// literals of ITS role once, from the role's row of an LDS table (g_klit, staged by the kernel), into a register set that stays live
+// across the episode loop: an LDS load at a wave-uniform address is wave-uniform for the compiler (scalar branches on what is
+// computed from it stay scalar), its result is a VGPR pair that cannot be rematerialised, and a VGPR operand needs no
+// constant-bus slot.  The generated text reads CITW_K(slot, literal): the register when the caller passed a set, the literal otherwise
+// (HAVE_K is a compile-time fact after inlining; a flag of its own because a comparison of the set's address with null is not one: null is a valid private address on this target) -- the lane-group kernels, at 254 / 256 VGPRs, pass none and compile what they always did.
+// (CitwKRegs, citw_no_kregs: serl_kregs.h)
+#define CITW_K(j, lit) (HAVE_K ? KR.k[j] : (lit))
+
 // Phase profile of the model evaluation (profiling builds only, -DCITW_PROFILE): shader-clock cycles of wave 0 of
 // workgroup 0 between the CITW_T marks of the generated code, accumulated in LDS and copied out by the kernel.
 #ifdef CITW_PROFILE

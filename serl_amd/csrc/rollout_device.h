@@ -29,6 +29,7 @@ struct RolloutArgs {
   uint32_t jitter, jitter_sites;      // hand-over stress builds only (citation_wave.h, -DCITW_JITTER): seed of the pseudo-random pauses (0 = none), classes of sites that pause
 };
 
+#include "serl_kregs.h"
 #define DET_FN __device__ __forceinline__
 #define DET_POW2(k) __longlong_as_double((long long)((k) + 1023) << 52)
 
@@ -42,10 +43,21 @@ struct RolloutArgs {
 // callers pass (z in [0, 40] or [-104, 0]), so the specification's round-half-away through (long long) is ONE v_cvt_i32_f64 (truncation,
 // like the cast) on the branch the sign selects and k comes back through v_cvt_f64_i32 -- the same integers, without the 64-bit
 // conversion sequences (two of ~14 instructions under exec masks, and five for (double)k) the generic form compiles to.
+// DET_K(i, literal): the literal, or slot i of the caller's register set (citation_libm.h CitwKRegs; round 5): the actor wavefront of the
+// one-episode team kernel loads serl_det_klit once per episode -- 14 two-move literals per tanh, five tanh per forward pass, on the SIMD
+// it shares with the team's look-up wavefront.  HAVE_K is a compile-time fact after inlining; every other caller compiles the literals.
+#define DET_K(i, lit) (HAVE_K ? KR.k[i] : (lit))
+#define DET_KPARAMS , const bool HAVE_K = false, const CitwKRegs &KR = citw_no_kregs
+#define DET_KARGS , HAVE_K, KR
+enum { SERL_DET_NK = 14 };
+static __device__ const double serl_det_klit[SERL_DET_NK] = {
+  1.4426950408889634, 0.6931471803691238, 1.9082149292705877e-10,
+  0.16666666666666666, 0.041666666666666664, 0.008333333333333333, 0.001388888888888889, 0.0001984126984126984, 2.48015873015873e-05,
+  2.7557319223985893e-06, 2.755731922398589e-07, 2.505210838544172e-08, 2.08767569878681e-09, 1.6059043836821613e-10};
 template <int SIGN>
-static DET_FN double det_expm1_reduced(double z, int *kout)
+static DET_FN double det_expm1_reduced(double z, int *kout DET_KPARAMS)
 {
-  const double INVLN2 = 1.4426950408889634, LN2_HI = 0.6931471803691238, LN2_LO = 1.9082149292705877e-10;
+  const double INVLN2 = DET_K(0, 1.4426950408889634), LN2_HI = DET_K(1, 0.6931471803691238), LN2_LO = DET_K(2, 1.9082149292705877e-10);
   const double v = z * INVLN2;
 #if defined(SERL_DET_K64) && SERL_DET_K64      // (A/B builds: the specification's form as written)
   const long long k64 = v < 0.0 ? -(long long)(0.5 - v) : (long long)(v + 0.5);
@@ -59,16 +71,16 @@ static DET_FN double det_expm1_reduced(double z, int *kout)
   /* expm1(r) - r = r^2 P(r), P of degree 11 with the Taylor coefficients 1/2! .. 1/13!, in Estrin form (dependency depth
    * 7 instead of 24: a lone GPU wavefront waits out every dependent operation) */
   const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
-  const double b0 = 0.5 + 0.16666666666666666 * r, b1 = 0.041666666666666664 + 0.008333333333333333 * r;
-  const double b2 = 0.001388888888888889 + 0.0001984126984126984 * r, b3 = 2.48015873015873e-05 + 2.7557319223985893e-06 * r;
-  const double b4 = 2.755731922398589e-07 + 2.505210838544172e-08 * r, b5 = 2.08767569878681e-09 + 1.6059043836821613e-10 * r;
+  const double b0 = 0.5 + DET_K(3, 0.16666666666666666) * r, b1 = DET_K(4, 0.041666666666666664) + DET_K(5, 0.008333333333333333) * r;
+  const double b2 = DET_K(6, 0.001388888888888889) + DET_K(7, 0.0001984126984126984) * r, b3 = DET_K(8, 2.48015873015873e-05) + DET_K(9, 2.7557319223985893e-06) * r;
+  const double b4 = DET_K(10, 2.755731922398589e-07) + DET_K(11, 2.505210838544172e-08) * r, b5 = DET_K(12, 2.08767569878681e-09) + DET_K(13, 1.6059043836821613e-10) * r;
   const double c0 = b0 + b1 * r2, c1 = b2 + b3 * r2, c2 = b4 + b5 * r2;
   const double p = (c0 + c1 * r4) + c2 * r8;
   *kout = k;
   return r + r2 * p;
 }
 
-static DET_FN float det_tanhf(float xf)
+static DET_FN float det_tanhf(float xf DET_KPARAMS)
 {
   if (xf != xf) return xf;
   const double x = (double)xf;
@@ -77,7 +89,7 @@ static DET_FN float det_tanhf(float xf)
   // are those of the specification:  k == 0: q / (q + 2);  else 1 - 2 / (2^k (q + 1) + 1);  |x| > 20: 1
   const double axc = ax > 20.0 ? 20.0 : ax;
   int k;
-  const double q = det_expm1_reduced<1>(axc + axc, &k);
+  const double q = det_expm1_reduced<1>(axc + axc, &k DET_KARGS);
   const bool small = k == 0;
   const double num = small ? q : 2.0;
   const double den = small ? q + 2.0 : DET_POW2(k) * (q + 1.0) + 1.0;
@@ -87,13 +99,13 @@ static DET_FN float det_tanhf(float xf)
   return (float)(x < 0.0 ? -t : t);
 }
 
-static DET_FN float det_expm1f_neg(float xf)     /* x <= 0 (the ELU branch) */
+static DET_FN float det_expm1f_neg(float xf DET_KPARAMS)     /* x <= 0 (the ELU branch) */
 {
   if (xf != xf) return xf;
   const double x = (double)xf;
   if (x < -104.0) return -1.0f;
   int k;
-  const double q = det_expm1_reduced<-1>(x, &k);
+  const double q = det_expm1_reduced<-1>(x, &k DET_KARGS);
   return (float)(k == 0 ? q : DET_POW2(k) * (q + 1.0) - 1.0);
 }
 
@@ -157,10 +169,10 @@ static DET_FN void serl_ref_generate(const serl_ref_spec *r, double t, double t_
   r0 = th * D2R; r1 = ph * D2R; r2 = 0.0 * D2R;
 }
 
-static __device__ __forceinline__ float serl_act(float v, int act)
+static __device__ __forceinline__ float serl_act(float v, int act DET_KPARAMS)
 {
-  if (act == SERL_ACT_TANH) return det_tanhf(v);
-  if (act == SERL_ACT_ELU) return v > 0.0f ? v : det_expm1f_neg(v);
+  if (act == SERL_ACT_TANH) return det_tanhf(v DET_KARGS);
+  if (act == SERL_ACT_ELU) return v > 0.0f ? v : det_expm1f_neg(v DET_KARGS);
   return v > 0.0f ? v : 0.01f * v;
 }
 
@@ -849,7 +861,7 @@ static __device__ __forceinline__ void serl_stage_actor_lds(const serl_rollout_d
 // BC: the previous layer goes through the LDS row hx (64 floats, this wavefront's own) instead of v_readlane (above)
 template <bool BC, class Sync>
 static __device__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const float *lw_generic, const float obs[7],
-                                              float act_out[3], Sync &sync, float *hx = nullptr)
+                                              float act_out[3], Sync &sync, float *hx = nullptr DET_KPARAMS)
 {
   constexpr int H = SERL_LDS_ACTOR_H;
   const int L = __builtin_amdgcn_readfirstlane(dd.num_layers), act = __builtin_amdgcn_readfirstlane(dd.activation);
@@ -886,7 +898,7 @@ static __device__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const
 #pragma unroll
     for (int j = 0; j < 7; ++j) w0[j] = lw[j * H + i0];
     acc = serl_dot7(acc, w0, obs);
-    h = serl_act(acc, act);
+    h = serl_act(acc, act DET_KARGS);
   }
   CITW_T(22);
   sync.start(L + 2);
@@ -918,9 +930,9 @@ static __device__ void serl_actor_forward_lds(const serl_rollout_desc &dd, const
       const float d = acc - mean, dd2 = d * d;
       const float var = serl_tree_sum<H>(dd2, lane);
       const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
-      h = serl_act(gm * d / den + bt, act);
+      h = serl_act(gm * d / den + bt, act DET_KARGS);
     } else {
-      const float t = det_tanhf(acc);
+      const float t = det_tanhf(acc DET_KARGS);
 #pragma unroll
       for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, i);
     }

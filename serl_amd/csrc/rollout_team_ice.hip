@@ -24,6 +24,12 @@
 #ifndef CITW_ROLE_PRIO_MASK
 #define CITW_ROLE_PRIO_MASK 0x02
 #endif
+// Round 5: the LDS-actor kernel keeps every role's f64 literals -- the glue's, the coefficients of the short sincos / pow bodies, the actor's
+// activation polynomial -- in registers for the episode (citation_wave.h CITW_K, citation_libm.h CITW_LK, rollout_device.h DET_K): 143 -> 235 of
+// the 256 VGPRs two wavefronts per SIMD allow, 9 481 -> 8 747 static instructions (nominal).
+#ifndef SERL_TEAM_KREGS
+#define SERL_TEAM_KREGS 1
+#endif
 #include "citation_wave.h"
 #include "rollout_device.h"
 #include "gen/citation_ice_wave.inc"   // look-up descriptor tables (shared with the one-wave kernels)

@@ -490,3 +490,34 @@ def test_env_configurations_vs_reference_python(golden, name):
     np.testing.assert_array_equal(tr[:, 2 * S + A + 2].astype(np.int8), g[name + '_cost'])  # info['cost'] of every step
     np.testing.assert_allclose(o['actions'][0, :T, :A], g[name + '_u'], rtol=1e-5, atol=1e-7)
     assert not o['actions'][0, :T, A:].any()
+
+
+def test_short_libm_flavour_of_the_oracle_stays_within_libm_accuracy_of_the_pinned_one(golden):
+    """oracle/_build/libcitation_oracle_shortlibm.so (oracle/citation_rt.h CIT_SHORT_LIBM) is the C restatement with sin / cos / tan / pow
+    taken from the CPU build of the product's serl_amd/csrc/citation_libm.h -- the flavour the GPU parity tests compare with at ZERO
+    tolerance.  The flavour pinned to the reference binary is the glibc one; this test bounds the distance between the two: open loop
+    (3 000 steps of the native step(), every build whose code differs) <= 1e-9 relative per state, the episodic returns of the stable
+    shipped actors <= 1e-7, lengths and cost counts equal (/root/reference/envs/h2000_v90/citation.py:65-72, base/core/agent.py:63-138)."""
+    from oracle.dynamics import CitationDynamics
+    from oracle import rollout as R
+    rng = np.random.default_rng(5)
+    for build in ('h2000_v90', 'ice', 'cg_timed', 'gust', 'test'):
+        a, b = CitationDynamics(build), CitationDynamics(build, short_libm=True)
+        cmd = np.zeros(10)
+        worst = 0.0
+        for k in range(3000):
+            cmd[0] = 0.01 * np.sin(0.01 * k) + 0.002 * rng.standard_normal()
+            cmd[1] = 0.01 * np.cos(0.013 * k)
+            cmd[2] = 0.005 * np.sin(0.007 * k)
+            xa, xb = a.step(cmd), b.step(cmd)
+            worst = max(worst, float(np.max(np.abs(xa - xb) / (np.abs(xa) + 1e-3))))
+        assert worst <= 1e-9, (build, worst)
+    from serl_amd import refsignals
+    w = golden('actors')['serl50']
+    ref = refsignals.tabulate(*refsignals.base_reference(80), 80)
+    moe = list(range(0, len(w), 3))
+    a = R.rollout(w, NET['serl50'], moe, ref, t_max=80, threads=8)
+    b = R.rollout(w, NET['serl50'], moe, ref, t_max=80, threads=8, short_libm=True)
+    np.testing.assert_array_equal(a['length_steps'], b['length_steps'])
+    np.testing.assert_array_equal(a['cost_steps'], b['cost_steps'])
+    assert (np.abs(a['fitness'] - b['fitness']) <= 1e-7 * np.abs(a['fitness'])).all(), np.abs(a['fitness'] / b['fitness'] - 1).max()

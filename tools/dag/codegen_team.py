@@ -39,7 +39,7 @@ Usage: python tools/dag/codegen_team.py [variant ...] [--suffix=_tag]      (CITW
 """
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import build_dag, codegen
+import build_dag, codegen, symex
 from codegen import LOOKUPS, hexf
 
 LEAF = ('cf', 'ci', 'in', 'in_i', 'true', 'false')
@@ -90,6 +90,8 @@ POST_TASKS = int(os.environ.get('CITW_TEAM_POST_TASKS', 1))        # 1: the glue
 TASK_MAX = float(os.environ.get('CITW_TEAM_TASK_MAX', 50))         # a task heavier than this (cost units) is split at an inner node
 TASK_MIN = float(os.environ.get('CITW_TEAM_TASK_MIN', 12))         # ... into pieces no lighter than this; lighter shared sub-expressions are recomputed
 TASK_COMM = float(os.environ.get('CITW_TEAM_TASK_COMM', 24))       # cost units between "value stored" and "value usable on another wavefront" (LDS store, flag, poll, load)
+KREGS_MAX = int(os.environ.get('CITW_TEAM_KREGS_MAX', 48))                # ... at most this many per role (two VGPRs each)
+KREGS = int(os.environ.get('CITW_TEAM_KREGS', 1))                      # 1: f64 literals that cost two 32-bit moves go through CITW_K(slot, literal): registers loaded once per episode (citation_wave.h CitwKRegs) when the kernel passes them, the literal itself otherwise
 CW = dict(div=11, sqrt=15, sel=3, unord=2, table3=120)
 FN = dict(sc_sin=100, sc_cos=100, sin=100, cos=100, tan=120, exp=40, log10=60, log=60, atan=80, pow=250)
 
@@ -548,6 +550,91 @@ class TeamGen(codegen.Gen):
         self.task_makespan = max(finish.values()) if finish else 0.0
 
     # ---- libm phase for an explicit set of nodes (level-1 libm nodes among `needed`)
+    # ---- f64 literals as registers ------------------------------------------------------------------------------------
+    # An f64 literal whose low dword is not zero costs two 32-bit moves at EVERY use (the build disables the machine LICM: hoisted
+    # out of the stage loop as SGPR pairs they spilled), 15 % of the headline kernel's instructions in round 4.  The role of a
+    # wavefront is fixed for the episode, so each role gets a register set of its own: slot j of role b holds the j-th most
+    # executed literal of eval_w<b>.  The generated text says CITW_K(j, literal); with a register set (HAVE_K, a
+    # compile-time fact after inlining) that is KR.k[j] -- a VGPR pair loaded from the role's row of the LDS table before the
+    # episode loop: wave-uniform for the compiler (an LDS load at a uniform address), not rematerialisable, no constant-bus slot --
+    # and without one the literal itself, so the lane-group kernels (no registers to spare) compile exactly what they did.
+    _LIT = None
+
+    def assign_kregs(self, b, text):
+        import re, struct
+        if TeamGen._LIT is None:
+            TeamGen._LIT = re.compile(r'\(-0x1\.[0-9a-f]+p[+-]\d+\)|(?<![\w.])0x1\.[0-9a-f]+p[+-]\d+')
+        inline = {0.5, -0.5, 1.0, -1.0, 2.0, -2.0, 4.0, -4.0} | {float(i) for i in range(-16, 65)}
+
+        def val(tok):
+            return float.fromhex(tok.strip('()'))
+
+        def two_moves(x):
+            return x not in inline and (struct.unpack('<Q', struct.pack('<d', x))[0] & 0xffffffff) != 0
+        weight = collections.Counter()
+        depth, regions = 0, []          # (depth at entry, weight factor)
+        for line in text.split('\n'):
+            w = 6.0
+            for d0, f in regions:
+                w = min(w, f)
+            if re.match(r'\s*if \(stage == 0\) \{', line):
+                regions.append((depth, 1.0))
+            elif 'only the selects on this condition read these' in line:
+                regions.append((depth, 0.05))
+            for tok in TeamGen._LIT.findall(line):
+                if two_moves(val(tok)):
+                    weight[val(tok)] += w
+            depth += line.count('{') - line.count('}')
+            while regions and depth <= regions[-1][0]:
+                regions.pop()
+        # the coefficient blocks of the libm bodies this role runs (citation_libm.h CITW_LK(i, literal)) come first -- they sit at the head of
+        # the hand-over chains every wavefront waits for --, then the glue's literals by how often they execute
+        blocks = self.libm_kblocks()
+        order, base = [], {}
+        for fam, fns in (('citw_sincos', ('citw_sincos', 'citw_tan', 'citw_sin', 'citw_cos')), ('citw_pow', ('citw_pow',))):
+            if any(re.search(r'\b%s\(' % f, text) for f in fns) and len(order) + len(blocks[fam]) <= KREGS_MAX:
+                for f in fns:
+                    base[f] = len(order)
+                order += blocks[fam]
+        nlib = len(order)
+        glue = [x for x, _ in sorted(weight.items(), key=lambda kv: (-kv[1], kv[0]))][:max(0, KREGS_MAX - nlib)]
+        slot = {x: nlib + j for j, x in enumerate(glue)}
+        self.klit[b] = order + glue
+
+        def sub(m):
+            x = val(m.group(0))
+            return 'CITW_K(%d, %s)' % (slot[x], m.group(0)) if x in slot else m.group(0)
+        text = TeamGen._LIT.sub(sub, text)
+        # ... and every call of such a body is told where its block starts
+        for f, kb in base.items():
+            out, pos = [], 0
+            for m in re.finditer(r'\b%s\(' % f, text):
+                i, depth = m.end(), 1
+                while depth:
+                    depth += {'(': 1, ')': -1}.get(text[i], 0)
+                    i += 1
+                out.append(text[pos:i - 1] + ', HAVE_K, KR, %d)' % kb)
+                pos = i
+            text = ''.join(out) + text[pos:]
+        return text
+
+    _KBLOCKS = None
+
+    def libm_kblocks(self):
+        """{function: [coefficient, ...]} of serl_amd/csrc/citation_libm.h, slot order (CITW_LK(i, literal))"""
+        if TeamGen._KBLOCKS is None:
+            import re
+            src = open(os.path.join(build_dag.ROOT, 'serl_amd', 'csrc', 'citation_libm.h')).read()
+            blocks, cur = {}, None
+            for line in src.split('\n'):
+                m = re.match(r'CITW_LIBM_FN \w+ (\w+)\(', line)
+                if m:
+                    cur = m.group(1)
+                for i, lit in re.findall(r'CITW_LK\((\d+), (-?0x1\.[0-9a-f]+p[+-]\d+)\)', line):
+                    blocks.setdefault(cur, {})[int(i)] = float.fromhex(lit)
+            TeamGen._KBLOCKS = {f: [d[i] for i in range(len(d))] for f, d in blocks.items()}
+        return TeamGen._KBLOCKS
+
     def libm_plan(self, needed):
         calls = {}
         for n in self.order:
@@ -930,7 +1017,7 @@ class TeamGen(codegen.Gen):
                 if sp is not None:
                     B('#endif')
 
-            B('static __device__ CITW_EVAL_INLINE double citw_%s_team_eval_w%d(const int stage, const double T, const unsigned TICK, const unsigned FSEQ, const double XL)' % (V, b))
+            B('static __device__ CITW_EVAL_INLINE double citw_%s_team_eval_w%d(const int stage, const double T, const unsigned TICK, const unsigned FSEQ, const double XL, const bool HAVE_K = false, const CitwKRegs &KR = citw_no_kregs)' % (V, b))
             B('{')
             B('  const CitwSearch (*S)[64] = g_S; const CitwLookup (*L)[2][64] = g_L;')
             B('  const bool major = stage == 0;')
@@ -1235,17 +1322,29 @@ class TeamGen(codegen.Gen):
             text = re.sub(r'\bg_y\[(\d+)\]', r'g_y[CITW_YOFF + \1]', text)
             text = re.sub(r'\b(citw_spec_pre<[^>]*>|citw_spec_tail<[^>]*>|citw_search<[^>]*>|citw_search_part<[^>]*>|citw_lookup2d<\d+>|citw_lookup2d_part<[^>]*>|citw_lookup1d<\d+>|citw_lookup1d_part<[^>]*>)\(0, ', r'\1(CITW_TROW, ', text)
             text = text.replace('const int lane = threadIdx.x & 63;', 'const int lane = CITW_LANE;')
+            if KREGS:
+                text = self.assign_kregs(b, text)
             return text
 
+        self.klit = {}
         for b in range(K - 1, -1, -1):
             P(function(b))
         P('/* wave-uniform dispatch: each wavefront of the team executes exactly one of the parts and its two barriers */')
-        P('static __device__ __forceinline__ double citw_%s_team_eval(const int wave, const int stage, const double T, const unsigned TICK, const unsigned FSEQ, const double XL)' % V)
+        P('static __device__ __forceinline__ double citw_%s_team_eval(const int wave, const int stage, const double T, const unsigned TICK, const unsigned FSEQ, const double XL, const bool HAVE_K = false, const CitwKRegs &KR = citw_no_kregs)' % V)
         P('{')
         for b in range(K - 1):
-            P('  if (wave == %d) return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ, XL);' % (b, V, b))
-        P('  return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ, XL);' % (V, K - 1))
+            P('  if (wave == %d) return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ, XL, HAVE_K, KR);' % (b, V, b))
+        P('  return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ, XL, HAVE_K, KR);' % (V, K - 1))
         P('}')
+        if KREGS:
+            nk = max(1, max(len(v) for v in self.klit.values()))
+            P('/* the f64 literals behind CITW_K(slot, literal): row b = the register set of role b (citation_wave.h CitwKRegs; staged into LDS by the kernels that use it) */')
+            P('enum { citw_%s_team_NKLIT = %d };' % (V, nk))
+            P('static __device__ const double citw_%s_team_klit[%d][%d] = {' % (V, K, nk))
+            for b in range(K):
+                row = [symex.f2b(x) for x in self.klit[b]]
+                P('  {%s},' % ', '.join([hexf(v) for v in row] + ['0.0'] * (nk - len(row))))
+            P('};')
         ks = sorted(self.kslot.items(), key=lambda kv: kv[1])
         if ks:
             P('#define CITW_TEAM_HAS_K 1')

@@ -1,0 +1,51 @@
+#!/bin/bash
+# One parametrised GPU session (replaces the per-session tools/gpu_round*_*.sh scripts of rounds 3 / 4):
+#   gpurun --timeout 1500 -- 'bash tools/gpu_session.sh <tag> <step> [<step> ...]'     -> gpurun_out/<tag>/...
+# steps (run in the order given):
+#   tests            the whole GPU suite (pytest -m gpu)
+#   ab:<lib,...>     tools/ab.py on each library (product = "default"; others by the tag of serl_amd/csrc/libserl_amd_<tag>.so), twice each,
+#                    150 episodes of the SERL50 shape; AB_E / AB_ACTORS override
+#   bench            the driver's command (bench.py, defaults)
+#   bench:<args>     bench.py with the given arguments (commas for spaces), e.g. bench:--workload,serl10,--no-cpu-baseline
+#   pmc              the SQ issue counters + FETCH / WRITE sizes of one evaluation (separate passes, MI355X_MICROARCH.md)
+#   profile          tools/profile_round.sh <tag> (the round's whole profile series)
+#   py:<script.py>   any script of the repo
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+for STEP in "$@"; do
+  case $STEP in
+    tests)
+      timeout 1500 python -m pytest tests -x -q -m gpu --timeout=600 > $O/pytest_gpu.txt 2>&1
+      tail -n 4 $O/pytest_gpu.txt ;;
+    ab:*)
+      for L in $(echo ${STEP#ab:} | tr ',' ' '); do
+        for rep in 1 2; do
+          if [ $L = default ]; then timeout 300 python tools/ab.py ${AB_E:-150} >> $O/ab.txt 2>> $O/err.txt
+          else SERL_LIB=$R/serl_amd/csrc/libserl_amd_$L.so timeout 300 python tools/ab.py ${AB_E:-150} >> $O/ab.txt 2>> $O/err.txt; fi
+        done
+      done
+      cut -c1-200 $O/ab.txt ;;
+    bench)
+      timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 1500 $O/bench.json ;;
+    bench:*)
+      A=$(echo ${STEP#bench:} | tr ',' ' '); N=$(echo ${STEP#bench:} | tr -c 'a-zA-Z0-9' '_')
+      timeout 900 python bench.py $A > $O/bench$N.json 2> $O/bench$N.err; tail -c 600 $O/bench$N.json ;;
+    pmc)
+      (cd /tmp && export TMPDIR=/tmp
+       P1="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
+       timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o pf -- $P1 > $O/pmc_fetch.log 2>&1
+       timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o pw -- $P1 > $O/pmc_write.log 2>&1
+       timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES -d $O/pmc_sq -o ps -- $P1 > $O/pmc_sq.log 2>&1)
+      for k in fetch write sq; do python tools/pmc_summary.py $O/pmc_$k > $O/pmc_$k.json 2>> $O/err.txt; rm -rf $O/pmc_$k; done
+      cat $O/pmc_sq.json | cut -c1-600 ;;
+    profile)
+      bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1 ;;
+    py:*)
+      timeout 900 python ${STEP#py:} > $O/$(basename ${STEP#py:} .py).txt 2>> $O/err.txt; tail -n 5 $O/$(basename ${STEP#py:} .py).txt ;;
+  esac
+done
+[ -f $O/err.txt ] && tail -n 3 $O/err.txt
+true
