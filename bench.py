@@ -51,6 +51,17 @@ def make_population(pop, rank, seed=7, tag='serl50'):
     return w
 
 
+def fp64_measured(ach_f64):
+    """the FP64 peak as MEASURED on an MI355X (tools/valu_latency.hip fma_peak: v_fma_f64 on every CU, 16 wavefronts per CU, 16 independent
+    chains per lane; profiles/valu_latency_current.json, refreshed by tools/distill_profiles.py) beside the datasheet figure"""
+    try:
+        v = json.load(open(os.path.join(ROOT, 'profiles', 'valu_latency_current.json')))
+        pk = float(v['fp64_fma_peak_tflops_measured'])
+        return {'peak_measured': pk, 'frac_of_measured_peak': ach_f64 / (pk * 1e12), 'peak_measured_source': 'profiles/valu_latency_current.json (tools/valu_latency.hip fma_peak)'}
+    except Exception:
+        return {'peak_measured': None}
+
+
 def cpu_port(w, hidden, ref, moe, faults_of=None, build_of=None):
     """The C restatement (oracle/rollout_ref.c) on all host cores, the same workload (the whole evaluation once)."""
     from oracle import rollout as R
@@ -59,18 +70,20 @@ def cpu_port(w, hidden, ref, moe, faults_of=None, build_of=None):
     cores = host_cores()              # (affinity mask capped by the cgroup CPU quota: the GPU box shows 256 logical CPUs, 16 cores' worth usable)
     net = dict(state_dim=7, action_dim=3, hidden=hidden, num_layers=3, activation='tanh')
     E = len(moe)
-    R.rollout(w, net, moe[:cores], ref[:cores], t_max=80.0, threads=cores)       # warm-up (page-in, lib build)
+    R.rollout(w, net, moe[:cores], ref[:cores], t_max=80.0, threads=cores, short_libm=True)       # warm-up (page-in, lib build)
     fit, ls = np.zeros(E), np.zeros(E, np.int32)
     t0 = time.perf_counter()
     groups = {None: np.arange(E)} if build_of is None else {b: np.nonzero(np.asarray(build_of) == b)[0] for b in dict.fromkeys(build_of)}
     for b, idx in groups.items():
-        o = R.rollout(w, net, moe[idx], ref[idx], t_max=80.0, threads=cores, **({} if b is None else dict(build=b, faults=[faults_of[e] for e in idx])))
+        # (the same-libm flavour of the checker, oracle/citation_rt.h CIT_SHORT_LIBM: the kernels' own sin / cos / tan / pow compiled for the CPU, so
+        # that parity_vs_cpu_port is a bit-for-bit statement; its speed is that of the glibc flavour, libm is a percent of a step)
+        o = R.rollout(w, net, moe[idx], ref[idx], t_max=80.0, threads=cores, short_libm=True, **({} if b is None else dict(build=b, faults=[faults_of[e] for e in idx])))
         fit[idx], ls[idx] = o['fitness'], o['length_steps']
     dt = time.perf_counter() - t0
     steps = int(ls.sum())
     return dict(value=steps / dt, unit='env-steps/s', cores=cores, kind='port',
                 sample='all %d episodes (8001 steps each) of the same workload, C restatement '
-                       '(oracle/rollout_ref.c) on %d threads, %.1f s wall' % (E, cores, dt)), fit, ls
+                       '(oracle/rollout_ref.c, same-libm flavour) on %d threads, %.1f s wall' % (E, cores, dt)), fit, ls
 
 
 def cpu_baseline(w, hidden, ref, moe, faults_of=None, build_of=None):
@@ -131,6 +144,7 @@ def main():
     ap.add_argument('--lanes', type=int, default=0, help='episodes per wavefront (0 = auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-partition-check', action='store_true')
+    ap.add_argument('--strong-legs', choices=['auto', 'on', 'off'], default='auto', help='append the strong-scaling legs (pop=512, mixed pop=2048) to the line: auto = when N > 1 and no --total-pop / --pop')
     ap.add_argument('--dry-partition', action='store_true', help='print the member / episode blocks of every rank for --gpus N [--total-pop M | --pop P] and exit: no GPU, no launcher')
     a = ap.parse_args()
     if a.dry_partition:
@@ -145,7 +159,9 @@ def main():
         covered = sorted(m for b in blocks for m in range(*b['members']))
         print(json.dumps({'dry_partition': True, 'n_gpus': a.gpus, 'scaling': 'strong' if a.total_pop > 0 else 'weak', 'total_pop': total,
                           'num_evals': ne_, 'blocks': blocks, 'covers_every_member_once': covered == list(range(total)),
-                          'gather': 'one all_gather of [num_evals, ceil(pop / world), 6] f64 rows per evaluation (serl_amd/distributed.py gather_rows)'}))
+                          'gather': 'one all_gather of [num_evals, ceil(pop / world), 6] f64 rows per evaluation (serl_amd/distributed.py gather_rows)',
+                          'strong_scaling_legs': [dict(leg, blocks=[list(sd_.member_block(leg['total_pop'], a.gpus, r)) for r in range(a.gpus)]) for leg in strong_legs(a, a.gpus)],
+                          'strong_scaling_note': STRONG_NOTE if strong_legs(a, a.gpus) else None}))
         return
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(a)
@@ -153,7 +169,6 @@ def main():
     import torch
     import torch.distributed as dist
     import serl_amd
-    from serl_amd import refsignals, metrics, builds, distributed as sd
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -163,6 +178,51 @@ def main():
     grouped = 'WORLD_SIZE' in os.environ          # under a launcher, also with one rank: the RCCL path is the one that runs
     if grouped:
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    ctx = dict(rank=rank, world=world, local=local, dev=dev, grouped=grouped, eng=serl_amd.RolloutEngine(local))
+    res = measure(a, ctx)
+    # The driver's N-GPU command carries no --total-pop: on its own it is the WEAK-scaling line of the metric's configuration (pop = 50
+    # per GPU).  BASELINE config 4 -- the one numeric target of north_star: ONE population of 512 sharded over the node, base/core/agent.py:234-256 --
+    # and config 5 (mixed-fault sweep, pop = 2 048) are strong-scaling questions, so the same run appends them as short legs (a few evaluations each,
+    # every rank in the same process group, the partition checked against one GPU), without touching the timed region above.
+    legs = strong_legs(a, world)
+    if legs:
+        out = []
+        for leg in legs:
+            a2 = argparse.Namespace(**dict(vars(a), **leg, no_cpu_baseline=True))
+            r2 = measure(a2, ctx)
+            if rank == 0:
+                out.append({k: r2[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling', 'kernel_ms', 't_step_us', 'config',
+                                               'partition_invariance', 'rccl') if k in r2})
+        if rank == 0:
+            res['strong_scaling_legs'] = out
+            res['strong_scaling_note'] = STRONG_NOTE
+    if rank == 0:
+        print(json.dumps(res))
+    if grouped:
+        dist.destroy_process_group()
+
+
+STRONG_NOTE = ('`value` of this line is WEAK scaling: every GPU evaluates its own pop = 50 (150 episodes, one per CU-resident team; 106 CUs idle).  STRONG scaling of pop = 50 is '
+               'flat by construction -- 150 / N episodes per GPU take the same kernel time as 150 (each episode owns a CU and is latency-bound; ceil-blocks give 7,7,7,7,7,7,7,1 members '
+               'on 8 ranks) -- so the strong-scaling figures are the legs: one population of 512 (BASELINE config 4) and the mixed-fault sweep of 2 048 (config 5) sharded by member.')
+
+
+def strong_legs(a, world):
+    """the strong-scaling legs `bench.py --gpus N` (N > 1, no --total-pop) appends to its line; --strong-legs on / off forces or drops them"""
+    if a.strong_legs == 'off' or a.total_pop > 0 or a.workload != 'serl50' or a.pop:
+        return []
+    if a.strong_legs != 'on' and world <= 1:
+        return []
+    return [dict(workload='serl50', total_pop=512, steps=3, warmup=1), dict(workload='mixed', total_pop=2048, steps=2, warmup=1)]
+
+
+def measure(a, ctx):
+    """W warm-up evaluations, K timed ones (barrier + synchronize on both sides, MAX over ranks), the bench line's dict on rank 0 (None elsewhere)"""
+    import torch
+    import torch.distributed as dist
+    import serl_amd
+    from serl_amd import refsignals, metrics, builds, distributed as sd
+    rank, world, local, dev, grouped = ctx['rank'], ctx['world'], ctx['local'], ctx['dev'], ctx['grouped']
 
     wl = WORKLOADS[a.workload]
     spec = serl_amd.NetSpec(7, 3, wl['hidden'], 3, 'tanh')
@@ -182,7 +242,7 @@ def main():
         ref_host = refsignals.synthetic_reference_tables(pop * ne, ne, 80, seed=7 + 100000 * rank)
         gather_pop = pop * world
     E = pop * ne
-    eng = serl_amd.RolloutEngine(local)
+    eng = ctx['eng']
     w = w_host.to(dev)
     ref = torch.from_numpy(ref_host).to(dev)
     moe = np.repeat(np.arange(pop, dtype=np.int32), ne)
@@ -201,7 +261,7 @@ def main():
             # flag is read in one_step, in front of the all-gather, and the general path taken if it says otherwise
             guess = metrics.calc_smoothness_speculative(out['actions'], ls)      # (None: the last evaluation of this shape had early endings)
             if guess is None:
-                sm = metrics.calc_smoothness(out['actions'], ls)
+                sm = metrics.calc_smoothness_after_miss(out['actions'], ls)      # (takes the mark back when this batch is full again)
             else:
                 sm = guess[0]
                 pending.append((guess[1], out['actions']))
@@ -267,8 +327,7 @@ def main():
     else:
         steps_total = float(steps_local)
     if rank != 0:
-        dist.destroy_process_group()
-        return
+        return None
     value = steps_total * a.steps / dt
     res_extra = {}
     if world > 1 and not a.no_partition_check:
@@ -321,7 +380,14 @@ def main():
                               '`..._full_dag` against every node of the DAG; defined for one episode per team (episodes <= CUs)'
                               % (fl['glue_instructions_min_trimmed'], fl['glue_instructions_min'])}
         pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_current.json')))
-        if pm.get('workload') == a.workload and pm.get('pop') == pop and ne == 3 and a.lanes == 0 and not strong:
+        from serl_amd import build as hip_build
+        here = hip_build.source_hash()
+        if fl.get('csrc_sha256') != here:
+            issue['floors_note'] = 'floors computed for another state of the kernel sources (profiles/floors_current.json csrc_sha256 != this tree): the DAG floors are properties of the model and move little, the fractions are quoted against them as they are'
+        if pm.get('workload') == a.workload and pm.get('pop') == pop and ne == 3 and a.lanes == 0 and not strong and pm.get('csrc_sha256') != here:
+            traffic = None             # the committed counters were collected on other kernel sources: not quoted (tools/profile_round.sh + tools/distill_profiles.py refresh them)
+            issue['sq_counters'] = 'stale: profiles/pmc_current.json belongs to csrc_sha256 %s, this tree is %s' % (str(pm.get('csrc_sha256'))[:12], here[:12])
+        elif pm.get('workload') == a.workload and pm.get('pop') == pop and ne == 3 and a.lanes == 0 and not strong:
             traffic = pm.get('traffic_bytes_per_launch')
             issue['sq_counters'] = dict({k: pm['issue'][k] for k in ('active_frac', 'wait_frac', 'issue_stall_frac', 'simd_issue_frac',
                                                                     'valu_per_env_step', 'salu_per_env_step', 'lds_per_env_step') if k in pm.get('issue', {})},
@@ -347,8 +413,8 @@ def main():
                      'note': 'path is instruction-issue / dependent-latency bound (DESIGN.md), not HBM-bound: algorithmic traffic is '
                              '48 B per env-step; achieved = steps x 48 B / kernel time; traffic = bytes per launch from '
                              'profiles/pmc_current.json (2 x FETCH_SIZE + WRITE_SIZE)'},
-        'roofline_fp64': {'bound': 'valu-f64', 'achieved': ach_f64 / 1e12, 'peak': FP64_PEAK / 1e12, 'unit': 'TFLOP/s',
-                          'frac': ach_f64 / FP64_PEAK},
+        'roofline_fp64': dict({'bound': 'valu-f64', 'achieved': ach_f64 / 1e12, 'peak': FP64_PEAK / 1e12, 'unit': 'TFLOP/s',
+                               'frac': ach_f64 / FP64_PEAK}, **fp64_measured(ach_f64)),
         'roofline_issue': issue,
         't_step_us': t_step_us,
         # SURVEY 8(d) words the metric "incl. H2D of weights / refs"; the bench contract of this build forbids a PCIe-inclusive rate as
@@ -366,11 +432,9 @@ def main():
         res['cpu_baseline'] = cb
         fit_gpu = fit.cpu().numpy()[:n_chk]
         rel = np.abs(fit_gpu - fit_cpu) / np.abs(fit_cpu)
-        res['parity_vs_cpu_port'] = {'max_rel_fitness': float(rel.max()), 'episodes_checked': int(n_chk),
+        res['parity_vs_cpu_port'] = {'max_rel_fitness': float(rel.max()), 'episodes_bit_identical': int((fit_gpu == fit_cpu).sum()), 'episodes_checked': int(n_chk),
                                      'lengths_equal': bool((ls.cpu().numpy()[:n_chk] == ls_cpu).all())}
-    print(json.dumps(res))
-    if grouped:
-        dist.destroy_process_group()
+    return res
 
 
 if __name__ == '__main__':

@@ -78,7 +78,7 @@ def div_const(x, c, rc):
 
 
 def libm(kind, x, c=0.0):
-    """citw_sincos (kind 0) / citw_tan (1) / citw_pow(x, c) (2) of serl_amd/csrc/citation_libm.h on the GPU"""
+    """citw_sincos (kind 0) / citw_tan (1) / citw_pow(x, c) (2) / citw_atan (3) of serl_amd/csrc/citation_libm.h on the GPU"""
     import torch
     xt = torch.as_tensor(x, dtype=torch.float64).cuda().contiguous()
     o0, o1 = torch.empty_like(xt), torch.empty_like(xt)

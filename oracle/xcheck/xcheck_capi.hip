@@ -17,25 +17,23 @@ static thread_local std::string g_xerr;
 
 // ---- unit checks of product device functions (tests/test_gpu_rollout.py): arrays in, arrays out ----------------------------------
 #include "citation_libm.h"
-// x / c by the reciprocal + fma correction of the product (citation_wave.h: citw_div_const; restated here with the same four
-// operations -- the header itself declares the kernels' LDS) and by the IEEE division
+// x / c by the reciprocal + fma correction of the product (citation_libm.h: citw_div_const, the function the generated kernels call) and by
+// the IEEE division
 __global__ void xcheck_div_const_kernel(const double *x, int n, double c, double rc, double *fast, double *ieee)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const double q = x[i] * rc;
-  const double r = __builtin_fma(-q, c, x[i]);
-  const double q2 = __builtin_fma(r, rc, q);
-  fast[i] = __builtin_amdgcn_div_fixup(q2, c, x[i]);
+  fast[i] = citw_div_const(x[i], c, rc);
   ieee[i] = x[i] / c;
 }
-// kind 0: citw_sincos -> (o0, o1); 1: citw_tan -> o0; 2: citw_pow(x, c) -> o0
+// kind 0: citw_sincos -> (o0, o1); 1: citw_tan -> o0; 2: citw_pow(x, c) -> o0; 3: citw_atan -> o0
 __global__ void xcheck_libm_kernel(int kind, const double *x, int n, double c, double *o0, double *o1)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   if (kind == 0) citw_sincos(x[i], &o0[i], &o1[i]);
   else if (kind == 1) o0[i] = citw_tan(x[i]);
+  else if (kind == 3) o0[i] = citw_atan(x[i]);
   else o0[i] = citw_pow(x[i], c);
 }
 

@@ -35,6 +35,20 @@ def _deps():
     return out
 
 
+def source_hash():
+    """SHA-256 over the kernel sources (serl_amd/csrc/**.hip|.h|.inc, include/serl_amd.h, the build flags): what a measurement of the library belongs to.
+    tools/profile_round.sh records it next to the counters it collects, tools/distill_profiles.py stores it in profiles/pmc_current.json and
+    floors_current.json, and bench.py quotes those numbers only while it still matches the tree it runs from."""
+    import hashlib
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    for f in sorted(_deps()):
+        if os.sep + 'build' + os.sep in f or '_role_isa' in f or '_exp' in os.path.basename(f):
+            continue
+        h.update(os.path.relpath(f, os.path.dirname(HERE)).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False, extra_flags=(), lib=None, tag=''):
     """extra_flags / lib / tag build a variant next to the product library (e.g. the phase-profiling build:
     extra_flags=['-DCITW_PROFILE'], lib='libserl_amd_prof.so', tag='_prof')."""
@@ -54,7 +68,7 @@ def build(force=False, verbose=False, extra_flags=(), lib=None, tag=''):
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
+    with ThreadPoolExecutor(max_workers=min(len(UNITS), max(4, 4 * (os.cpu_count() or 8)))) as ex:      # (hipcc spends most of its time waiting on its own sub-processes)
         objs = list(ex.map(cc, UNITS))
     r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs,
                        capture_output=True, text=True)
@@ -82,7 +96,7 @@ def build_variant(lib, tag, extra_flags, units, force=False):
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (unit, r.stderr[-4000:]))
         return obj
-    with ThreadPoolExecutor(max_workers=len(units)) as ex:
+    with ThreadPoolExecutor(max_workers=min(len(units), max(4, 4 * (os.cpu_count() or 8)))) as ex:
         mine = list(ex.map(cc, units))
     objs = mine + [os.path.join(objdir, u.replace('.hip', '.o')) for u in UNITS if u not in units]
     r = subprocess.run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', path] + objs, capture_output=True, text=True)
@@ -99,6 +113,9 @@ def build_jitter(force=False):
 
 
 if __name__ == '__main__':
+    if '--source-hash' in sys.argv:
+        print(source_hash())
+        sys.exit(0)
     print(build(force='--force' in sys.argv, verbose=True))
     if '--jitter' in sys.argv:
         print(build_jitter(force='--force' in sys.argv))

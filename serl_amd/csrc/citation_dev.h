@@ -109,7 +109,7 @@ __shared__ double g_B[SERL_LDS_B_SLOTS * CIT_MAX_NB];
 #define LIFT_SIN(x) citw_sin(x)
 #define LIFT_COS(x) citw_cos(x)
 #define LIFT_TAN(x) citw_tan(x)
-#define LIFT_ATAN(x) atan(x)
+#define LIFT_ATAN(x) citw_atan(x)
 #define LIFT_ATAN2(x, y) atan2(x, y)
 #define LIFT_ASIN(x) asin(x)
 #define LIFT_ACOS(x) acos(x)

@@ -160,3 +160,50 @@ CITW_LIBM_FN double citw_pow(const double x, const double c CITW_LIBM_KPARAMS)
   const double em1 = __builtin_fma(r * r, e, r);                        // exp(r) - 1
   return __builtin_ldexp(1.0 + em1, (int)kd);
 }
+
+// atan x (the gust / test builds' turbulence model; round 5): the published fdlibm algorithm (s_atan.c) -- argument reduction to
+// |t| < 7/16 around 0, atan(1/2), atan(1), atan(3/2), infinity (one division), an odd/even split of a degree-11 minimax polynomial in
+// t^2, atan(breakpoint) added as hi + lo.  + - x / only, no fused operation: the CPU build and the kernels return the same bits (the
+// same-libm flavour of the oracle relies on that), < 1 ulp.
+CITW_LIBM_FN double citw_atan(const double x0)
+{
+  const double AT0 = 0x1.555555555550dp-2, AT1 = -0x1.999999998ebc4p-3, AT2 = 0x1.24924920083ffp-3, AT3 = -0x1.c71c6fe231671p-4,
+               AT4 = 0x1.745cdc54c206ep-4, AT5 = -0x1.3b0f2af749a6dp-4, AT6 = 0x1.10d66a0d03d51p-4, AT7 = -0x1.dde2d52defd9ap-5,
+               AT8 = 0x1.97b4b24760debp-5, AT9 = -0x1.2b4442c6a6c2fp-5, AT10 = 0x1.0ad3ae322da11p-6;
+  if (x0 != x0) return x0;
+  const double ax = __builtin_fabs(x0);
+  if (ax >= 0x1.0p+66) return x0 < 0.0 ? -(0x1.921fb54442d18p+0 + 0x1.1a62633145c07p-54) : (0x1.921fb54442d18p+0 + 0x1.1a62633145c07p-54);
+  double t, hi = 0.0, lo = 0.0;
+  int id = -1;
+  if (ax < 0.4375) {
+    if (ax < 0x1.0p-29) return x0;
+    t = x0;
+  } else if (ax < 1.1875) {
+    if (ax < 0.6875) { id = 0; t = (2.0 * ax - 1.0) / (2.0 + ax); hi = 0x1.dac670561bb4fp-2; lo = 0x1.a2b7f222f65e2p-56; }
+    else { id = 1; t = (ax - 1.0) / (ax + 1.0); hi = 0x1.921fb54442d18p-1; lo = 0x1.1a62633145c07p-55; }
+  } else {
+    if (ax < 2.4375) { id = 2; t = (ax - 1.5) / (1.0 + 1.5 * ax); hi = 0x1.f730bd281f69bp-1; lo = 0x1.007887af0cbbdp-56; }
+    else { id = 3; t = -1.0 / ax; hi = 0x1.921fb54442d18p+0; lo = 0x1.1a62633145c07p-54; }
+  }
+  const double z = t * t, w = z * z;
+  const double s1 = z * (AT0 + w * (AT2 + w * (AT4 + w * (AT6 + w * (AT8 + w * AT10)))));
+  const double s2 = w * (AT1 + w * (AT3 + w * (AT5 + w * (AT7 + w * AT9))));
+  if (id < 0) return t - t * (s1 + s2);
+  const double r = hi - ((t * (s1 + s2) - lo) - t);
+  return x0 < 0.0 ? -r : r;
+}
+
+#ifdef __HIPCC__
+// x / c for a literal c, rc = RN(1 / c): correctly rounded for every finite x whose quotient is a normal number -- proved per
+// divisor by tools/dag/constdiv.py (error of q + r rc against x / c below 2^-104; the finitely many x whose quotient lies that
+// close to a rounding boundary are enumerated and checked exactly), so the result is the IEEE quotient the reference computes.
+// v_div_fixup_f64 restores the IEEE result for zeros (sign), infinities and NaN.  4 instructions, ~30 dependent cycles
+// (IEEE division: 13 and ~71).  fma is explicit here; -ffp-contract=off only forbids the compiler to fuse on its own.
+static __device__ __forceinline__ double citw_div_const(const double x, const double c, const double rc)
+{
+  const double q = x * rc;
+  const double r = __builtin_fma(-q, c, x);
+  const double q2 = __builtin_fma(r, rc, q);
+  return __builtin_amdgcn_div_fixup(q2, c, x);
+}
+#endif

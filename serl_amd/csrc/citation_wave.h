@@ -265,10 +265,18 @@ __shared__ alignas(64) double g_y[32 * CITW_GROUPS];   // team kernels: values t
 // Phase profile of the model evaluation (profiling builds only, -DCITW_PROFILE): shader-clock cycles of wave 0 of
 // workgroup 0 between the CITW_T marks of the generated code, accumulated in LDS and copied out by the kernel.
 #ifdef CITW_PROFILE
+// (the marks of role r fire on the hardware wavefront that RUNS role r -- rollout_team_<v>.hip maps roles to wavefronts; units without a map: role = wavefront)
+#ifdef CITW_PROF_TEAM_ROLES      // (one-episode team units: rollout_team.inc defines the map; wavefront 7 is the actor)
+static __device__ __forceinline__ int serl_team_role(const bool stream);
+#define CITW_PROF_ROLE() ((threadIdx.x >> 6) < 7 ? serl_team_role(false) : 8)
+#else
+#define CITW_PROF_ROLE() ((int)(threadIdx.x >> 6))
+#endif
+#define CITW_PROF_IS(r) (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && CITW_PROF_ROLE() == (r))
 __shared__ unsigned long long g_prof[32];
 __shared__ unsigned long long g_tlast;
-#define CITW_T0() do { if (blockIdx.x == 0 && threadIdx.x == 0) g_tlast = __builtin_readcyclecounter(); } while (0)
-#define CITW_T(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+#define CITW_T0() do { if (CITW_PROF_IS(0)) g_tlast = __builtin_readcyclecounter(); } while (0)
+#define CITW_T(k) do { if (CITW_PROF_IS(0)) { const unsigned long long t_ = __builtin_readcyclecounter(); \
                          g_prof[(k)] += t_ - g_tlast; g_tlast = t_; } } while (0)
 __shared__ unsigned long long g_tlast1;       // same for wave 1 of the team kernels
 __shared__ unsigned long long g_tlastw[16];    // ... and for the other waves (barrier arrival / departure only)
@@ -292,17 +300,17 @@ static __device__ __forceinline__ constexpr int citw_mark_k(int s) { return s ==
 #define CITW_U(k) ((void)0)
 #define CITW_W0(w) ((void)0)
 #define CITW_W(w, k) ((void)0)
-#define CITW_V0(w) do { if (blockIdx.x == 0 && threadIdx.x == 64 * (w)) g_tlastw[(w)] = __builtin_readcyclecounter(); } while (0)
-#define CITW_V(w, k) do { if (blockIdx.x == 0 && threadIdx.x == 64 * (w)) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+#define CITW_V0(w) do { if (CITW_PROF_IS(w)) g_tlastw[(w)] = __builtin_readcyclecounter(); } while (0)
+#define CITW_V(w, k) do { if (CITW_PROF_IS(w)) { const unsigned long long t_ = __builtin_readcyclecounter(); \
                          g_prof[(k)] += t_ - g_tlastw[(w)]; g_tlastw[(w)] = t_; } } while (0)
 #else
 #define CITW_V0(w) ((void)0)
 #define CITW_V(w, k) ((void)0)
-#define CITW_U0() do { if (blockIdx.x == 0 && threadIdx.x == 64) g_tlast1 = __builtin_readcyclecounter(); } while (0)
-#define CITW_U(k) do { if (blockIdx.x == 0 && threadIdx.x == 64) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+#define CITW_U0() do { if (CITW_PROF_IS(1)) g_tlast1 = __builtin_readcyclecounter(); } while (0)
+#define CITW_U(k) do { if (CITW_PROF_IS(1)) { const unsigned long long t_ = __builtin_readcyclecounter(); \
                          g_prof[(k)] += t_ - g_tlast1; g_tlast1 = t_; } } while (0)
-#define CITW_W0(w) do { if (blockIdx.x == 0 && threadIdx.x == 64 * (w)) g_tlastw[(w)] = __builtin_readcyclecounter(); } while (0)
-#define CITW_W(w, k) do { if (blockIdx.x == 0 && threadIdx.x == 64 * (w)) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+#define CITW_W0(w) do { if (CITW_PROF_IS(w)) g_tlastw[(w)] = __builtin_readcyclecounter(); } while (0)
+#define CITW_W(w, k) do { if (CITW_PROF_IS(w)) { const unsigned long long t_ = __builtin_readcyclecounter(); \
                          g_prof[(k)] += t_ - g_tlastw[(w)]; g_tlastw[(w)] = t_; } } while (0)
 #endif
 #else
@@ -723,18 +731,8 @@ static __device__ __forceinline__ void citw_lookup1d_pass(const int wv, const Ci
   out[wv][d.out] = r + y0;
 }
 
-// x / c for a literal c, rc = RN(1 / c): correctly rounded for every finite x whose quotient is a normal number -- proved per
-// divisor by tools/dag/constdiv.py (error of q + r rc against x / c below 2^-104; the finitely many x whose quotient lies that
-// close to a rounding boundary are enumerated and checked exactly), so the result is the IEEE quotient the reference computes.
-// v_div_fixup_f64 restores the IEEE result for zeros (sign), infinities and NaN.  4 instructions, ~30 dependent cycles
-// (IEEE division: 13 and ~71).  fma is explicit here; -ffp-contract=off only forbids the compiler to fuse on its own.
-static __device__ __forceinline__ double citw_div_const(const double x, const double c, const double rc)
-{
-  const double q = x * rc;
-  const double r = __builtin_fma(-q, c, x);
-  const double q2 = __builtin_fma(r, rc, q);
-  return __builtin_amdgcn_div_fixup(q2, c, x);
-}
+// (citw_div_const -- x / c for a literal c in four instructions -- lives in citation_libm.h, free of LDS declarations, so that the device unit
+// check of oracle/xcheck exercises the shipped text)
 
 // ---- look-up lanes with the hint-dependent half PRECOMPUTED (single-episode team kernels, wave 0).  Of a 2-D interpolation
 //     a = (z10 - z00) / dx * (u0 - x0) + z00,  b = (z11 - z01) / dx * (u0 - x0) + z01,  r = (b - a) / dy * (u1 - y0) + a

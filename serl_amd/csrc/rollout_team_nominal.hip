@@ -27,6 +27,7 @@
 // Round 5: the LDS-actor kernel keeps every role's f64 literals -- the glue's, the coefficients of the short sincos / pow bodies, the actor's
 // activation polynomial -- in registers for the episode (citation_wave.h CITW_K, citation_libm.h CITW_LK, rollout_device.h DET_K): 143 -> 235 of
 // the 256 VGPRs two wavefronts per SIMD allow, 9 481 -> 8 747 static instructions (nominal).
+#define CITW_PROF_TEAM_ROLES 1      // profiling builds: the marks of role r fire on the hardware wavefront that runs it (citation_wave.h CITW_PROF_IS)
 #ifndef SERL_TEAM_KREGS
 #define SERL_TEAM_KREGS 1
 #endif

@@ -354,9 +354,7 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
             raise RuntimeError('reference table too short: %d episodes were still running after %d steps' % (int((ls < 0).sum()), T_ref))
     if need_actions:
         hit = spec_sm is not None and metrics.smoothness_speculation_result(out['actions'], spec_sm[1])
-        sm = (spec_sm[0] if hit else metrics.calc_smoothness(out['actions'], ls)).cpu().numpy()
-        if spec_sm is None and (np.abs(ls) == out['actions'].shape[1]).all():
-            metrics._SPEC_MISS.discard(tuple(out['actions'].shape[:2]))      # (full again: guess next time)
+        sm = (spec_sm[0] if hit else (metrics.calc_smoothness_after_miss if spec_sm is None else metrics.calc_smoothness)(out['actions'], ls)).cpu().numpy()
     else:
         sm = np.zeros(E)
     fit = ret + sm if smooth_fitness else ret.copy()

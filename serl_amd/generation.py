@@ -93,7 +93,14 @@ def evaluate_generation(pop: Sequence, rl_agent=None, *, args, mode='nominal', t
     if n_pop == 0 and rl_agent is None:
         # (evaluate_generation_sharded: a rank whose member block is empty and no RL episode to fly -- nothing to launch)
         z = np.zeros((ne, 0))
-        T0 = refsignals.n_steps_for(t_max)
+        # the staged rows must have the T every other rank stages (gather_stored_episodes sizes its all_gather from the local T): the table's
+        # when references are tables, the clock's when they are specs or the base reference -- the same rule as the normal path below
+        if refs is not None and not (isinstance(refs, np.ndarray) and refs.dtype.names is not None):
+            rt = torch.as_tensor(refs)
+            assert rt.dim() in (2, 3) and rt.shape[-1] == 3, 'reference tables are [T, 3] or [episodes, T, 3]'
+            T0 = int(rt.shape[-2])
+        else:
+            T0 = refsignals.n_steps_for(t_max)
         res = PopResult(fitness=z, returns=z, smoothness=z, length_steps=z.astype(np.int32), length_t=z, cost_steps=z.astype(np.int32),
                         pop_fitness=np.zeros(0), champion=-1, worst=-1, kernel_ms=0.0, episode_member=np.zeros(0, np.int32))
         g = GenerationResult(pop=res, rl_episode=None, kernel_ms=0.0)

@@ -1,6 +1,7 @@
 """Episode metrics of the reference, batched on the device with torch.fft (rocFFT):
 calc_smoothness (base/core/utils.py:82-120) and calc_nMAE (base/core/utils.py:39-58)."""
 import math
+import numpy as np
 import torch
 
 
@@ -63,6 +64,8 @@ def _smoothness_full(y, N, dt):
     wq = _WQ.get(key)
     if wq is None:
         freq = torch.linspace(dt, 1 / (2 * dt), M, dtype=torch.float64, device=y.device)
+        if len(_WQ) >= 8:                      # (a handful of episode lengths per process at most; never grow without bound)
+            _WQ.pop(next(iter(_WQ)))
         wq = _WQ[key] = torch.sqrt(freq).repeat_interleave(2 * A)
     Yv = Yr.reshape(E, K * A * 2)[:, 2 * A:(M + 1) * 2 * A]                    # bins 1 .. N/2 - 1: a strided 2-D view, no copy
     nrm = torch.linalg.vector_norm(Yv * wq, dim=1)                              # sqrt(sum_i f_i sum_j |Y_ij|^2)
@@ -97,6 +100,18 @@ def smoothness_speculation_result(actions, all_full):
     else:
         _SPEC_MISS.add((E, T))
     return ok
+
+
+def calc_smoothness_after_miss(actions, length_steps, dt=0.01):
+    """The general path for a batch whose shape calc_smoothness_speculative refused to guess (a miss is remembered per shape) -- and the place
+    where the mark is taken back: when every episode of THIS batch flew the whole table again, the next one is guessed again.  One helper for
+    every caller (evaluator.evaluate_pop, bench.py), so that none of them keeps paying the host round trip after a single early ending."""
+    sm = calc_smoothness(actions, length_steps, dt)
+    E, T, _ = actions.shape
+    full = (length_steps.abs() == T).all() if torch.is_tensor(length_steps) else (np.abs(np.asarray(length_steps)) == T).all()
+    if bool(full):                             # (calc_smoothness has waited for the lengths already: this read costs nothing more)
+        _SPEC_MISS.discard((E, T))
+    return sm
 
 
 def _smoothness_dft(actions, lengths, dt):

@@ -19,8 +19,8 @@ from oracle import rollout as R
 from core.mod_neuro_evo import SSNE
 
 
-def gene(sd, h, act):
-    return types.SimpleNamespace(actor=refshim.make_actor({k: v.clone() for k, v in sd.items()}, h, 3, act))
+def gene(sd, h, act, layers=3):
+    return types.SimpleNamespace(actor=refshim.make_actor({k: v.clone() for k, v in sd.items()}, h, layers, act))
 
 
 def main():
@@ -57,5 +57,48 @@ def main():
     print(sorted(out))
 
 
+def main_tiny():
+    """ga_cross_tiny.npz (round 5): crossover_inplace PINNED.  On the shipped actor shape the reference's inclusive random.randint
+    (mod_neuro_evo.py:76,89) raises IndexError in 200 of 200 seeded trials -- with 32-row matrices and up to 64 draws per matrix an
+    out-of-range row is practically certain -- so the operator is pinned on a shape where whole runs complete: a tiny Actor (hidden 4,
+    one hidden layer: 8 parameter tensors, 3 .. 4 rows each), python `random` seeded with the first seeds whose run draws no
+    out-of-range row.  Stored: the two parents (packed f32 rows), and for every such seed both children after the reference's OWN
+    SSNE.crossover_inplace(gene1, gene2)."""
+    H, L, act = 4, 1, 'tanh'
+    import argparse
+    from core.genetic_agent import Actor
+    args = argparse.Namespace(hidden_size=H, num_layers=L, activation_actor=act, state_dim=7, action_dim=3, device=torch.device('cpu'))
+    torch.manual_seed(11)
+    parents = [Actor(args).state_dict() for _ in range(2)]
+    for sd in parents:      # (the custom LayerNorm starts as ones / zeros: give the 1-D tensors distinct values, they cross over too)
+        for k, v in sd.items():
+            if v.dim() == 1:
+                v.copy_(torch.randn_like(v) * 0.3)
+    fake = types.SimpleNamespace(regularize_weight=lambda w, mag: torch.clamp(w, -mag, mag),
+                                 args=types.SimpleNamespace(test_ea=False, _verbose_crossover=False))
+    out = {'net': np.array([7, 3, H, L], np.int32), 'parents': np.stack([R.pack_state_dict(sd) for sd in parents])}
+    seeds = []
+    for seed in range(20000):
+        g1, g2 = gene(parents[0], H, act, L), gene(parents[1], H, act, L)
+        random.seed(seed)
+        try:
+            SSNE.crossover_inplace(fake, g1, g2)
+        except IndexError:
+            continue
+        a, b = R.pack_state_dict(g1.actor.state_dict()), R.pack_state_dict(g2.actor.state_dict())
+        if (a == out['parents'][0]).all() and (b == out['parents'][1]).all():
+            continue                      # (a run that drew zero cross-overs everywhere pins nothing)
+        out['seed%d_a' % seed], out['seed%d_b' % seed] = a, b
+        seeds.append(seed)
+        if len(seeds) == 8:
+            break
+    out['seeds'] = np.array(seeds, np.int32)
+    np.savez_compressed(os.path.join(HERE, 'ga_cross_tiny.npz'), **out)
+    print('seeds that complete in the reference:', seeds)
+
+
 if __name__ == '__main__':
-    main()
+    if '--tiny' in sys.argv:
+        main_tiny()
+    else:
+        main()

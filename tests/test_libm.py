@@ -66,3 +66,22 @@ def test_pow_of_the_temperature_ratio_against_long_double(host):
     x = rng.uniform(0.8, 1.2, 1000); y = np.empty_like(x)
     host.host_pow(x.ctypes.data_as(D), ctypes.c_double(100.0), y.ctypes.data_as(D), len(x))
     np.testing.assert_allclose(y, np.power(x, 100.0), rtol=3e-16)
+
+
+def test_atan_against_long_double(host):
+    """citw_atan (the gust / test builds' one call; the published fdlibm algorithm): every reduction interval, the breakpoints, tiny, huge
+    and non-finite arguments -- < 1 ulp against 80-bit long double"""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-0.45, 0.45, 300_000), rng.uniform(-3, 3, 500_000), rng.uniform(-50, 50, 200_000), 10.0 ** rng.uniform(-12, 20, 100_000),
+                        [0.0, -0.0, 0.4375, 0.6875, 1.1875, 2.4375, -0.4375, -2.4375, 1e-10, 2.0 ** 66, -2.0 ** 70, np.inf, -np.inf]])
+    y = np.empty_like(x)
+    host.host_atan(x.ctypes.data_as(D), y.ctypes.data_as(D), len(x))
+    e = _ulp(y, np.arctan(x.astype(np.longdouble)))
+    fin = x != 0
+    assert e[fin].max() <= 1.0 and e[fin].mean() < 0.3, (e[fin].max(), e[fin].mean())
+    z0, z1 = y[-13], y[-12]                    # atan(+0) = +0, atan(-0) = -0
+    assert z0 == 0.0 and not np.signbit(z0) and z1 == 0.0 and np.signbit(z1)
+    np.testing.assert_array_equal(y[-2:], [np.pi / 2, -np.pi / 2])
+    z = np.array([np.nan]); w = np.empty_like(z)
+    host.host_atan(z.ctypes.data_as(D), w.ctypes.data_as(D), 1)
+    assert np.isnan(w[0])

@@ -403,7 +403,7 @@ class Gen:
         return '  const double v%d = g_inv[wv][%d];' % (n, k)
 
     BIN = dict(add='+', sub='-', mul='*', div='/', gt='>', ge='>=', lt='<', le='<=', eq='==', ne='!=')
-    FN1 = dict(sqrt='sqrt', exp='exp', log10='log10', log='log', sin='citw_sin', cos='citw_cos', tan='citw_tan', atan='atan', asin='asin',
+    FN1 = dict(sqrt='sqrt', exp='exp', log10='log10', log='log', sin='citw_sin', cos='citw_cos', tan='citw_tan', atan='citw_atan', asin='asin',
                acos='acos', floor='floor', fabs='fabs')
 
     _cdiv = {}
@@ -709,7 +709,7 @@ class Gen:
                 cond = '(lane >= %d && lane < %d)' % (j, k) if k - j > 1 else '(lane == %d)' % j
                 if k - j == 1 and j in self.call_guard:
                     cond = '(lane == %d && %s%s)' % (j, '' if self.call_guard[j][1] else '!', self.ref(self.call_guard[j][0]))
-                call = {'sincos': 'citw_sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = citw_pow(a_, %s)' % hexf(prm), 'tan': 'r0_ = citw_tan(a_)'}.get(fn, 'r0_ = %s(a_)' % fn)
+                call = {'sincos': 'citw_sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = citw_pow(a_, %s)' % hexf(prm), 'tan': 'r0_ = citw_tan(a_)'}.get(fn, 'r0_ = %s(a_)' % {'atan': 'citw_atan'}.get(fn, fn))
                 P('    %sif %s { %s; }' % ('' if first else 'else ', cond, call))
                 first = False
                 j = k

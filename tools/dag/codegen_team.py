@@ -91,6 +91,8 @@ TASK_MAX = float(os.environ.get('CITW_TEAM_TASK_MAX', 50))         # a task heav
 TASK_MIN = float(os.environ.get('CITW_TEAM_TASK_MIN', 12))         # ... into pieces no lighter than this; lighter shared sub-expressions are recomputed
 TASK_COMM = float(os.environ.get('CITW_TEAM_TASK_COMM', 24))       # cost units between "value stored" and "value usable on another wavefront" (LDS store, flag, poll, load)
 KREGS_MAX = int(os.environ.get('CITW_TEAM_KREGS_MAX', 48))                # ... at most this many per role (two VGPRs each)
+FMA = int(os.environ.get('CITW_TEAM_FMA', 0))                            # TIMING EXPERIMENT (results change): products feeding an add / sub on the same wavefront fused into fma
+KREGS_ONE_MOVE = int(os.environ.get('CITW_TEAM_KREGS_ONE_MOVE', 1))        # 1: ... literals that cost ONE move (low dword zero) too, behind the others (r05b / r05d: 15.26 -> 15.03 us per env step together with the unpadded g_w)
 KREGS = int(os.environ.get('CITW_TEAM_KREGS', 1))                      # 1: f64 literals that cost two 32-bit moves go through CITW_K(slot, literal): registers loaded once per episode (citation_wave.h CitwKRegs) when the kernel passes them, the literal itself otherwise
 CW = dict(div=11, sqrt=15, sel=3, unord=2, table3=120)
 FN = dict(sc_sin=100, sc_cos=100, sin=100, cos=100, tan=120, exp=40, log10=60, log=60, atan=80, pow=250)
@@ -584,6 +586,8 @@ class TeamGen(codegen.Gen):
             for tok in TeamGen._LIT.findall(line):
                 if two_moves(val(tok)):
                     weight[val(tok)] += w
+                elif KREGS_ONE_MOVE and val(tok) not in inline:
+                    weight[val(tok)] += 0.5 * w       # (one 32-bit move: its high dword; they fill what a role leaves of the set -- the set's size is the largest role's)
             depth += line.count('{') - line.count('}')
             while regions and depth <= regions[-1][0]:
                 regions.pop()
@@ -634,6 +638,31 @@ class TeamGen(codegen.Gen):
                     blocks.setdefault(cur, {})[int(i)] = float.fromhex(lit)
             TeamGen._KBLOCKS = {f: [d[i] for i in range(len(d))] for f, d in blocks.items()}
         return TeamGen._KBLOCKS
+
+    # ---- TIMING EXPERIMENT (CITW_TEAM_FMA=1; results change in the last bits): every add / sub one of whose operands is a product computed
+    # by the same wavefront becomes an fma -- what would a "fast DAG" specification buy?
+    def fuse_fma(self, text):
+        import re
+        OPND = r'(?:CITW_K\(\d+, \(?-?0x[0-9a-fp.+-]+\)?\)|\(-?0x[0-9a-fp.+-]+\)|-?0x[0-9a-fp.+-]+|[A-Za-z_]\w*)'
+        mul = {}
+        for m in re.finditer(r'^  const double (v\d+) = (%s) \* (%s);$' % (OPND, OPND), text, re.M):
+            mul[m.group(1)] = (m.group(2), m.group(3))
+        n = [0]
+
+        def sub(m):
+            name, a, op, b = m.group(1), m.group(2), m.group(3), m.group(4)
+            if a in mul:
+                x, y = mul[a]
+                n[0] += 1
+                return '  const double %s = __builtin_fma(%s, %s, %s%s);' % (name, x, y, '-' if op == '-' else '', b)
+            if b in mul:
+                x, y = mul[b]
+                n[0] += 1
+                return '  const double %s = __builtin_fma(%s%s, %s, %s);' % (name, '-' if op == '-' else '', x, y, a)
+            return m.group(0)
+        text = re.sub(r'^  const double (v\d+) = (%s) ([+-]) (%s);$' % (OPND, OPND), sub, text, flags=re.M)
+        self.n_fused = getattr(self, 'n_fused', 0) + n[0]
+        return text
 
     def libm_plan(self, needed):
         calls = {}
@@ -826,7 +855,7 @@ class TeamGen(codegen.Gen):
                     B('    const int j_ = %s-1;' % ''.join('lane == %d ? %d : ' % (g.nodes[k_[1]][2], i_) for i_, k_ in enumerate(keys)))
                     B('    double r0_ = 0.0, r1_ = 0.0;')
                     B('    if (j_ >= 0) {')
-                    B('      %s;' % ('citw_sincos(XL, &r0_, &r1_)' if fn == 'sincos' else 'r0_ = %s(XL)' % {'tan': 'citw_tan'}.get(fn, fn)))
+                    B('      %s;' % ('citw_sincos(XL, &r0_, &r1_)' if fn == 'sincos' else 'r0_ = %s(XL)' % {'tan': 'citw_tan', 'atan': 'citw_atan'}.get(fn, fn)))
                     B('      g_m[%d][2 * (%d + j_)] = r0_; g_m[%d][2 * (%d + j_) + 1] = r1_;' % (b, lo, b, lo))
                     B('    }')
                     B('  }')
@@ -864,7 +893,7 @@ class TeamGen(codegen.Gen):
                     if k - i == 1 and calls[i] in self.call_guard:
                         gd = self.call_guard[calls[i]]
                         cond = '(l_ == %d && %s%s)' % (i, '' if gd[1] else '!', self.ref(gd[0]))
-                    call = {'sincos': 'citw_sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = citw_pow(a_, %s)' % hexf(prm), 'tan': 'r0_ = citw_tan(a_)'}.get(fn, 'r0_ = %s(a_)' % fn)
+                    call = {'sincos': 'citw_sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = citw_pow(a_, %s)' % hexf(prm), 'tan': 'r0_ = citw_tan(a_)'}.get(fn, 'r0_ = %s(a_)' % {'atan': 'citw_atan'}.get(fn, fn))
                     early = any(self.flag_of.get(nd, b) == 8 + b for nd in self.libm_calls[calls[i]][1].values())
                     if early and first:
                         # the first function's results leave at once, behind a flag of their own
@@ -915,7 +944,7 @@ class TeamGen(codegen.Gen):
                     while k < len(lst) and lst[k][0][0] == fn and (fn != 'pow' or lst[k][0][2] == prm):
                         k += 1
                     cond = '(lane >= %d && lane < %d)' % (j, k) if k - j > 1 else '(lane == %d)' % j
-                    call = {'sincos': 'citw_sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = citw_pow(a_, %s)' % hexf(prm), 'tan': 'r0_ = citw_tan(a_)'}.get(fn, 'r0_ = %s(a_)' % fn)
+                    call = {'sincos': 'citw_sincos(a_, &r0_, &r1_)', 'pow': 'r0_ = citw_pow(a_, %s)' % hexf(prm), 'tan': 'r0_ = citw_tan(a_)'}.get(fn, 'r0_ = %s(a_)' % {'atan': 'citw_atan'}.get(fn, fn))
                     B('    %sif %s { %s; }' % ('' if first else 'else ', cond, call))
                     first = False
                     j = k
@@ -1322,6 +1351,8 @@ class TeamGen(codegen.Gen):
             text = re.sub(r'\bg_y\[(\d+)\]', r'g_y[CITW_YOFF + \1]', text)
             text = re.sub(r'\b(citw_spec_pre<[^>]*>|citw_spec_tail<[^>]*>|citw_search<[^>]*>|citw_search_part<[^>]*>|citw_lookup2d<\d+>|citw_lookup2d_part<[^>]*>|citw_lookup1d<\d+>|citw_lookup1d_part<[^>]*>)\(0, ', r'\1(CITW_TROW, ', text)
             text = text.replace('const int lane = threadIdx.x & 63;', 'const int lane = CITW_LANE;')
+            if FMA:
+                text = self.fuse_fma(text)
             if KREGS:
                 text = self.assign_kregs(b, text)
             return text

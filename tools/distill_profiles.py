@@ -10,10 +10,13 @@ for n in ('serl50', 'total512', 'serl10', 'serl10_pop128', 'pop64', 'pop128', 'p
 for n in ('serl50', 'serl10_pop128', 'pop512'):
     shutil.copy('%s/kernel_stats_%s.md' % (O, n), '%s/%s_kernel_stats_%s.md' % (P, series, n))
 shutil.copy(O + '/valu_latency.json', '%s/%s_valu_latency.json' % (P, series))
+shutil.copy(O + '/valu_latency.json', P + '/valu_latency_current.json')      # bench.py: roofline_fp64.peak_measured
 shutil.copy(O + '/critical_path.json', '%s/%s_critical_path.json' % (P, series))
 open('%s/%s_cycle_profile.txt' % (P, series), 'w').write(''.join(open(O + '/' + f).read() for f in ('ab.txt', 'ab_prof1.txt', 'ab_prof2.txt') if __import__('os').path.exists(O + '/' + f)))
 shutil.copy(O + '/refill.json', '%s/%s_refill.json' % (P, series))
-shutil.copy(O + '/critical_path.json', P + '/floors_current.json')
+sha = open(O + '/csrc_sha256.txt').read().strip()      # serl_amd/build.py source_hash() of the tree that was measured
+floors = json.load(open(O + '/critical_path.json')); floors['csrc_sha256'] = sha
+json.dump(floors, open(P + '/floors_current.json', 'w'), indent=1)
 sq, pf, pw = (json.load(open('%s/pmc_%s.json' % (O, k))) for k in ('sq', 'fetch', 'write'))
 cp = json.load(open(O + '/critical_path.json'))
 b = json.loads(open('%s/%s_bench_serl50.json' % (P, series)).read())
@@ -28,7 +31,7 @@ pmc = dict(
     FETCH_SIZE_KB=pf['FETCH_SIZE'], WRITE_SIZE_KB=pw['WRITE_SIZE'], kernel_ms=[pf['kernel_ms'], pw['kernel_ms'], sq['kernel_ms']],
     corrections='MI355X_MICROARCH.md HBM section: rocprofv3 on gfx950 tallies FETCH_SIZE at half the bytes of the 128-B requests -> doubled; WRITE_SIZE as reported',
     traffic_bytes_per_launch=traffic, algorithmic_bytes_per_launch=steps * 48, ratio=traffic / (steps * 48),
-    sq={k: v for k, v in sq.items() if k != 'kernel_ms'})
+    sq={k: v for k, v in sq.items() if k != 'kernel_ms'}, csrc_sha256=sha)
 pmc['issue'] = dict(
     bound='valu-issue / dependent latency (63 of 64 lanes of every glue instruction carry the same scalar; two wavefronts per SIMD)',
     active_frac=sq['SQ_ACTIVE_INST_ANY'] / wc, wait_frac=sq['SQ_WAIT_ANY'] / wc, issue_stall_frac=sq['SQ_WAIT_INST_ANY'] / wc,

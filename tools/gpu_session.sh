@@ -34,6 +34,7 @@ for STEP in "$@"; do
       A=$(echo ${STEP#bench:} | tr ',' ' '); N=$(echo ${STEP#bench:} | tr -c 'a-zA-Z0-9' '_')
       timeout 900 python bench.py $A > $O/bench$N.json 2> $O/bench$N.err; tail -c 600 $O/bench$N.json ;;
     pmc)
+      python serl_amd/build.py --source-hash > $O/csrc_sha256.txt
       (cd /tmp && export TMPDIR=/tmp
        P1="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
        timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o pf -- $P1 > $O/pmc_fetch.log 2>&1

@@ -28,16 +28,18 @@ for r in range(K):
 extern "C" __global__ void __launch_bounds__(512) role%d(double *out, unsigned steps, double t0)
 {
   double acc = 0.0, xl = out[threadIdx.x & 63];
+  CitwKRegs kr;                                 // the role's f64 literals in registers, like rollout_team.inc loads them (ROLE_ISA_NOK=1: literals)
+  for (int j = 0; j < citw_nominal_team_NKLIT; ++j) kr.k[j] = g_x[j];
   for (unsigned fseq = 0; fseq < steps; ++fseq) {
 #pragma nounroll
     for (int st = 0; st < 6; ++st) {
-      acc += citw_nominal_team_eval_w%d(st, t0 + st, fseq, fseq, xl);
+      acc += citw_nominal_team_eval_w%d(st, t0 + st, fseq, fseq, xl, %s, kr);
       xl = g_f[0][st][threadIdx.x & 15] + acc;
     }
   }
   out[threadIdx.x] = acc;
 }
-''' % (r, r)
+''' % (r, r, 'false' if os.environ.get('ROLE_ISA_NOK') else 'true')
 path = os.path.join(B.CSRC, '_role_isa.hip')
 open(path, 'w').write(src)
 try:

@@ -8,6 +8,7 @@ TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
+(cd $R && python serl_amd/build.py --source-hash) > $O/csrc_sha256.txt      # what these measurements belong to (bench.py quotes them only while it matches)
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
 timeout 900 $B --steps 10 --warmup 3 > $O/bench_serl50.json 2> $O/bench_serl50.err
