@@ -750,13 +750,34 @@ struct CitwSpec {
   int sq;                                    // ... n | in << 8 | h << 16 | (h == stored) << 24
   double x0, sa, z00, sb, z01, y0, dy;       // table lane
   int tq;                                    // ... in0 | in1 << 8 | out << 16 | is1d << 24
+  double bx0, ba, by0;                       // second table lane (round 5): a 1-D table of round 1 -- x0, (y1 - y0) / (x1 - x0), y0
+  int bq;                                    // ... in0 | out << 8
 };
 
-template <int NS, int NT>
-static __device__ __forceinline__ CitwSpec citw_spec_pre(const int wv, const CitwSearch *S, const CitwLookup *L, const int lane)
+// the lanes, kept across evaluations by the kernels that can afford the registers (one-episode team: rollout_team.inc): valid until an
+// evaluation repairs an interval (the generated code clears it in front of the plain search)
+struct CitwSpecCache { CitwSpec p; bool valid; };
+static __device__ CitwSpecCache citw_no_spec_cache;      // what the default arguments bind when the caller keeps none (never touched: HAVE_SC is false there)
+
+// N1: the first N1 lanes also carry one 1-D table of round 1 each (descriptor row L1): until round 5 that pass ran on a helper wavefront BEHIND
+// the hint verification of this one (flag, poll, descriptor -> interval -> table: three dependent LDS round trips and a division on the path
+// to barrier B1); here its interval-dependent half -- everything but the last multiply-add -- is part of the cached lanes.
+template <int NS, int NT, int N1 = 0>
+static __device__ __forceinline__ CitwSpec citw_spec_pre(const int wv, const CitwSearch *S, const CitwLookup *L, const int lane, const CitwLookup *L1 = nullptr)
 {
-  static_assert(CITW_GROUP_LANES == 64 && NS <= 64 && NT <= 64, "one lane per search / table");
+  static_assert(CITW_GROUP_LANES == 64 && NS <= 64 && NT <= 64 && N1 <= 64, "one lane per search / table");
   CitwSpec p;
+  p.bx0 = p.ba = p.by0 = 0.0; p.bq = 0;
+  if (N1 > 0 && !(CITW_ABLATE_LOOK & 8)) {      // the operations of citw_lookup1d_pass, up to the quotient
+    const CitwLookup d = L1[lane < N1 ? lane : 0];
+    const int i = g_sidx[wv][d.sx];
+    const double *x = g_ro + d.xrw, *y = g_ro + d.zw;
+    const double x0 = x[i], x1 = x[i + 1], y0 = y[i], y1 = y[i + 1];
+    double r = y1 - y0;
+    r = r / (x1 - x0);
+    p.bx0 = x0; p.ba = r; p.by0 = y0;
+    p.bq = (int)d.in0 | (int)d.out << 8;
+  }
   if (CITW_ABLATE_LOOK & 8) { p.sxl = p.sxh = p.x0 = p.sa = p.z00 = p.sb = p.z01 = p.y0 = p.dy = 0.0; p.sq = p.tq = 0; return p; }
   {
     const CitwSearch d = S[lane < NS ? lane : 0];
@@ -788,20 +809,24 @@ static __device__ __forceinline__ CitwSpec citw_spec_pre(const int wv, const Cit
 
 // search lanes [S0, S1) verify, table lanes [T0, T1) interpolate and -- if every search lane confirmed its interval -- store;
 // returns whether a lane missed (wave-uniform): then nothing was stored and the caller runs the plain passes of the round
-template <int S0, int S1, int T0, int T1, typename OUT>
+template <int S0, int S1, int T0, int T1, int N1 = 0, typename OUT>
 static __device__ __forceinline__ bool citw_spec_tail(const int wv, const CitwSpec &p, OUT &out, const int lane)
 {
   if (CITW_ABLATE_LOOK & 8) return false;
   const double su = g_in[wv][(p.sq >> 8) & 255];
   const double u0 = g_in[wv][p.tq & 255], u1 = g_in[wv][(p.tq >> 8) & 255];
+  const double ub = N1 > 0 ? g_in[wv][p.bq & 255] : 0.0;
   const bool ok = citw_hint_ok((p.sq >> 16) & 255, p.sq & 255, p.sxl, p.sxh, su) && (p.sq >> 24) != 0;
   const double wx = u0 - p.x0;
   double a = p.sa * wx; a = a + p.z00;
   double b = p.sb * wx; b = b + p.z01;
   double r = b - a; r = r / p.dy; r = r * (u1 - p.y0);
   const double res = (p.tq >> 24) != 0 ? a : r + a;
+  double rb = p.ba * (ub - p.bx0);           // (citw_lookup1d_pass: r = r * (u - x0); out = r + y0)
+  rb = rb + p.by0;
   const bool miss = __ballot(lane >= S0 && lane < S1 && !ok) != 0ULL;
   if (!miss && lane >= T0 && lane < T1) out[wv][(p.tq >> 16) & 255] = res;
+  if (N1 > 0 && !miss && lane < N1) out[wv][(p.bq >> 8) & 255] = rb;
   CITW_WAVE_FENCE();
   return miss;
 }

@@ -11,7 +11,7 @@
 #include "rollout_device.h"
 #include "gen/citation_nominal_wave.inc"   // look-up descriptor tables (shared with the one-wave kernels)
 #ifndef CITW_TEAM_INC
-#define CITW_TEAM_INC "gen/citation_nominal_team.inc"      // (tools/exp_build.py: A/B builds around another generated file)
+#define CITW_TEAM_INC "gen/citation_nominal_teamg.inc"      // (tools/exp_build.py: A/B builds around another generated file)
 #endif
 #include CITW_TEAM_INC
 #define VARIANT nominal

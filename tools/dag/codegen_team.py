@@ -52,7 +52,8 @@ IMPORT_COST = float(os.environ.get('CITW_TEAM_IMPORT_COST', 0.0))         # unit
 # initial load per wave behind B1 (round 1, K = 4: the wave that hands the pow chain over needed a bias of 100 units; with two
 # wavefronts per SIMD the hardware evens that out and no bias measures best)
 POST_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_POST_BIAS', '0').split(',') if v]
-PRE_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_PRE_BIAS', '0,0,0,-100').split(',') if v]        # initial load per wave in front of B1 (negative: the wave takes more; wave 3 shares its SIMD with the mostly parked actor wavefront)
+PRE_BIAS_GROUPS = '0,0,0,-100'      # the lane-group kernels' partition (gen/citation_<v>_teamg.inc, --lane-groups): there wave 1 still runs round 1's 1-D interpolation pass
+PRE_BIAS = [float(v) for v in os.environ.get('CITW_TEAM_PRE_BIAS', PRE_BIAS_GROUPS if '--lane-groups' in sys.argv else '0,-200,0,-100').split(',') if v]        # initial load per wave in front of B1 (negative: the wave takes more; wave 3 shares its SIMD with the mostly parked actor wavefront)
 AFFINITY_POST = float(os.environ.get('CITW_TEAM_AFFINITY_POST', 0.0))
 SHARE_LIBM = int(os.environ.get('CITW_TEAM_SHARE_LIBM', 1))           # 1: every libm call is made by one wave, the others read the result (flag hand-over)
 SPREAD_IN = int(os.environ.get('CITW_TEAM_SPREAD_INPUTS', 0))         # 1: EVERY round-1 input cone runs on a helper; wave 0 waits for their input flags (g_iflag), then looks up
@@ -74,6 +75,7 @@ LIBM_WAVE = {kv.split(':')[0]: int(kv.split(':')[1]) for kv in os.environ.get('C
 EARLY_FLAG = int(os.environ.get('CITW_TEAM_EARLY_FLAG', 2))             # 2: the first libm function group of a wavefront (sincos in front of tan) is announced by a flag of its own, g_flag[8 + q] -- except on the wavefront of the handed-over chain (1: there too -- with lane groups that produced NaNs in the first launch of a process, r03 sweeps 39 / 41, cause not found; 0: off)
 TAN_MERGE = int(os.environ.get('CITW_TEAM_TAN_MERGE', 1))               # 1: the tan lanes of a wavefront ride its sincos pass and divide behind it (no second body)
 TWO_PASS = int(os.environ.get('CITW_TEAM_TWO_PASS', 1))                 # 1: a helper computes what needs no foreign libm result before its first flag wait, node by node
+SPEC_1D = int(os.environ.get('CITW_TEAM_SPEC_1D', 1))                  # 1: ... and round 1's 1-D tables ride those lanes too (one episode per team; no helper pass behind the hint verification)
 SPEC = int(os.environ.get('CITW_TEAM_SPEC', 1))                        # 1: emit the merged descriptor row + the precomputed look-up lanes of wave 0 (citw_spec_pre / citw_spec_tail; compiled in with -DCITW_SPEC_LOOKUP=1)
 STAGE0 = int(os.environ.get('CITW_TEAM_STAGE0', 1))                    # 1: glue that depends on the command vector alone runs in the first of the six evaluations only (its look-up inputs / exchanged values keep their LDS slots)
 OWN_LOOKUPS = int(os.environ.get('CITW_TEAM_OWN_LOOKUPS', 0))          # 1: the helper that computes a look-up input also searches / interpolates the (1-D) tables keyed on it: wave 0 never waits for it
@@ -90,7 +92,7 @@ POST_TASKS = int(os.environ.get('CITW_TEAM_POST_TASKS', 1))        # 1: the glue
 TASK_MAX = float(os.environ.get('CITW_TEAM_TASK_MAX', 50))         # a task heavier than this (cost units) is split at an inner node
 TASK_MIN = float(os.environ.get('CITW_TEAM_TASK_MIN', 12))         # ... into pieces no lighter than this; lighter shared sub-expressions are recomputed
 TASK_COMM = float(os.environ.get('CITW_TEAM_TASK_COMM', 24))       # cost units between "value stored" and "value usable on another wavefront" (LDS store, flag, poll, load)
-KREGS_MAX = int(os.environ.get('CITW_TEAM_KREGS_MAX', 48))                # ... at most this many per role (two VGPRs each)
+KREGS_MAX = int(os.environ.get('CITW_TEAM_KREGS_MAX', 24))                # ... at most this many per role (two VGPRs each)
 FMA = int(os.environ.get('CITW_TEAM_FMA', 0))                            # TIMING EXPERIMENT (results change): products feeding an add / sub on the same wavefront fused into fma
 KREGS_ONE_MOVE = int(os.environ.get('CITW_TEAM_KREGS_ONE_MOVE', 1))        # 1: ... literals that cost ONE move (low dword zero) too, behind the others (r05b / r05d: 15.26 -> 15.03 us per env step together with the unpadded g_w)
 KREGS = int(os.environ.get('CITW_TEAM_KREGS', 1))                      # 1: f64 literals that cost two 32-bit moves go through CITW_K(slot, literal): registers loaded once per episode (citation_wave.h CitwKRegs) when the kernel passes them, the literal itself otherwise
@@ -970,7 +972,14 @@ class TeamGen(codegen.Gen):
                 mine = [(k, n) for k, n in enumerate(R['ins']) if r != 0 or self.in_owner[n] == 0]
                 if r == 0 and b == 0 and self.spec is not None:
                     B('#if CITW_GROUP_LANES == 64 && CITW_SPEC_LOOKUP   /* the hint-dependent half of every look-up lane (all rounds), in front of the input cones it overlaps */')
-                    B('  const CitwSpec sp_ = citw_spec_pre<%d, %d>(%s, S[%d], L[%d][0], lane);' % (self.spec['NS'], self.spec['NT'], row, self.spec['tidx'], self.spec['tidx']))
+                    # Round 5: what citw_spec_pre computes depends on the STORED INTERVALS alone (g_sidx: descriptor, interval ends, four corners, the
+                    # x-direction quotients -- five dependent LDS round trips and two divisions per evaluation on the wavefront every other one
+                    # waits for), and an interval moves in 4 of 2 400 evaluations: with a cache (HAVE_SC: the caller keeps it for the episode) the
+                    # lanes are recomputed only behind an evaluation that had to repair an interval -- the same values, not computed again.
+                    n1s = n_l1(R) if (self.h1d is not None and SPEC_1D) else 0      # round 1's 1-D tables ride the same lanes (no helper pass behind the verification)
+                    pre = 'citw_spec_pre<%d, %d, %d>(%s, S[%d], L[%d][0], lane, L[%d][1])' % (self.spec['NS'], self.spec['NT'], n1s, row, self.spec['tidx'], self.spec['tidx'], R['tidx'])
+                    B('  if (HAVE_SC && !SC.valid) { SC.p = %s; SC.valid = true; }' % pre)
+                    B('  const CitwSpec sp_ = HAVE_SC ? SC.p : %s;' % pre)
                     B('#endif')
                 for k, n in mine:
                     emit_node(n, allowed)
@@ -999,15 +1008,21 @@ class TeamGen(codegen.Gen):
                     B('#if CITW_GROUP_LANES == 64 && CITW_SPEC_LOOKUP   /* one episode per team: the look-up lanes were precomputed on the stored intervals (citw_spec_pre above) */')
                     if r == 0:
                         B('  %s;' % TM(6))
-                    B('  if (citw_spec_tail<%d, %d, %d, %d>(%s, sp_, g_out%d, lane)) {   /* (rare) an interval moved: the plain passes, which repair the stored indices */'
-                      % (sp['ns'][ri] + sp['nt'][ri] + (row, R['oarr'])))
+                    n1s = n_l1(R) if (r == 0 and off1d and SPEC_1D) else 0
+                    B('  if (citw_spec_tail<%d, %d, %d, %d, %d>(%s, sp_, g_out%d, lane)) {   /* (rare) an interval moved: the plain passes, which repair the stored indices */'
+                      % (sp['ns'][ri] + sp['nt'][ri] + (n1s, row, R['oarr'])))
+                    B('    if (HAVE_SC) SC.valid = false;   /* the plain search rewrites g_sidx: the cached lanes are recomputed at the top of the next evaluation */')
                     B('    citw_search<%d, %d, %d>(%s, S[%d], lane);' % (sa + (row, R['tidx'])))
                     if R['L2']:
                         B('    citw_lookup2d<%d>(%s, L[%d][0], g_out%d, lane);' % (len(R['L2']), row, R['tidx'], R['oarr']))
                     if R['L1'] and r != 0:
                         B('    citw_lookup1d<%d>(%s, L[%d][1], g_out%d, lane);' % (len(R['L1']), row, R['tidx'], R['oarr']))
+                    if off1d and SPEC_1D:
+                        B('    citw_lookup1d<%d>(%s, L[%d][1], g_out%d, lane);' % (n_l1(R), row, R['tidx'], R['oarr']))
                     B('  }')
-                    if off1d:
+                    if off1d and SPEC_1D:
+                        pass                      # (nobody waits: the 1-D tables rode the lanes above)
+                    elif off1d:
                         B('  citw_iflag_raise(0, %s);   /* the interval indices in g_sidx[0] are verified: wave %d runs the 1-D pass */' % (SEQ, self.h1d))
                     elif r == 0 and R['L1']:
                         B('  citw_lookup1d<%d>(%s, L[%d][1], g_out%d, lane);' % (n_l1(R), row, R['tidx'], R['oarr']))
@@ -1046,7 +1061,7 @@ class TeamGen(codegen.Gen):
                 if sp is not None:
                     B('#endif')
 
-            B('static __device__ CITW_EVAL_INLINE double citw_%s_team_eval_w%d(const int stage, const double T, const unsigned TICK, const unsigned FSEQ, const double XL, const bool HAVE_K = false, const CitwKRegs &KR = citw_no_kregs)' % (V, b))
+            B('static __device__ CITW_EVAL_INLINE double citw_%s_team_eval_w%d(const int stage, const double T, const unsigned TICK, const unsigned FSEQ, const double XL, const bool HAVE_K = false, const CitwKRegs &KR = citw_no_kregs, const bool HAVE_SC = false, CitwSpecCache &SC = citw_no_spec_cache)' % (V, b))
             B('{')
             B('  const CitwSearch (*S)[64] = g_S; const CitwLookup (*L)[2][64] = g_L;')
             B('  const bool major = stage == 0;')
@@ -1235,6 +1250,8 @@ class TeamGen(codegen.Gen):
                 B('  citw_lookup1d_part<%d, 1, 2>(0, L[0][1], g_out0, lane);' % n1)
                 B('#endif')
             if b != 0 and b == self.h1d:
+                if SPEC_1D and self.spec is not None:
+                    B('#if !(CITW_GROUP_LANES == 64 && CITW_SPEC_LOOKUP)   /* (one episode per team: the 1-D tables ride wave 0\'s precomputed lanes) */')
                 B('  /* ---- the 1-D interpolation pass of round 1, taken over from wave 0 */')
                 R0_ = self.rounds[0]
                 wait_searches(b)
@@ -1243,6 +1260,8 @@ class TeamGen(codegen.Gen):
                     B('  citw_lookup1d_part<%d, 0, CITW_L1_SHARE(%d)>(0, L[0][1], g_out0, lane);   /* (16 lanes per episode: wave 3 takes the second pass) */' % (n1, n1))
                 else:
                     B('  citw_lookup1d<%d>(0, L[0][1], g_out0, lane);' % n_l1(self.rounds[0]))
+                if SPEC_1D and self.spec is not None:
+                    B('#endif')
             B('  %s;' % TM(0))
             B('  CITW_TEAM_BARRIER1();   /* B1: look-up results (g_out0) and exchanged values (g_x) are visible to every wave */')
             after_b1[0] = True
@@ -1361,11 +1380,11 @@ class TeamGen(codegen.Gen):
         for b in range(K - 1, -1, -1):
             P(function(b))
         P('/* wave-uniform dispatch: each wavefront of the team executes exactly one of the parts and its two barriers */')
-        P('static __device__ __forceinline__ double citw_%s_team_eval(const int wave, const int stage, const double T, const unsigned TICK, const unsigned FSEQ, const double XL, const bool HAVE_K = false, const CitwKRegs &KR = citw_no_kregs)' % V)
+        P('static __device__ __forceinline__ double citw_%s_team_eval(const int wave, const int stage, const double T, const unsigned TICK, const unsigned FSEQ, const double XL, const bool HAVE_K = false, const CitwKRegs &KR = citw_no_kregs, const bool HAVE_SC = false, CitwSpecCache &SC = citw_no_spec_cache)' % V)
         P('{')
         for b in range(K - 1):
-            P('  if (wave == %d) return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ, XL, HAVE_K, KR);' % (b, V, b))
-        P('  return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ, XL, HAVE_K, KR);' % (V, K - 1))
+            P('  if (wave == %d) return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ, XL, HAVE_K, KR, HAVE_SC, SC);' % (b, V, b))
+        P('  return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ, XL, HAVE_K, KR, HAVE_SC, SC);' % (V, K - 1))
         P('}')
         if KREGS:
             nk = max(1, max(len(v) for v in self.klit.values()))
@@ -1392,6 +1411,8 @@ def main():
         gen = TeamGen(v, waves=waves, hoist='--hoist-invariants' in sys.argv, lds_consts=int(os.environ.get('CITW_TEAM_LDS_CONSTS', 0)))
         text = gen.emit_team()
         suffix = next((a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--suffix=')), '')     # experiments: --suffix=_exp7
+        if '--lane-groups' in sys.argv and not suffix:
+            suffix = 'g'
         path = os.path.join(build_dag.ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_team%s.inc' % (v, suffix))
         open(path, 'w').write(text)
         print('%s: %d lines; %d waves; pre-barrier glue %s (load estimate %s), post %s (%s), exchanged %d, xdot owners %s'
