@@ -171,6 +171,27 @@ def test_bench_dry_partition_prints_the_member_blocks():
         assert d['covers_every_member_once'] and [b['members'] for b in d['blocks']] == want and d['scaling'] == 'strong'
 
 
+def test_bench_n_gpu_command_plans_the_strong_scaling_legs():
+    """The driver's N-GPU command is `bench.py --gpus N` with no --total-pop: the weak-scaling line of the metric's configuration.  It
+    appends the strong-scaling legs north_star asks about -- ONE population of 512 (BASELINE config 4, base/core/agent.py:234-256 cut into N
+    member blocks) and the mixed-fault sweep of 2 048 (config 5) -- and says that pop = 50 strong scaling is flat by construction.  The dry
+    run shows the plan without a GPU; with one rank, --total-pop or --pop there are no legs."""
+    import subprocess, json
+
+    def dry(*args):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--dry-partition'] + list(args), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    d = dry('--gpus', '2')
+    legs = d['strong_scaling_legs']
+    assert [(l['workload'], l['total_pop']) for l in legs] == [('serl50', 512), ('mixed', 2048)]
+    assert legs[0]['blocks'] == [[0, 256], [256, 512]] and legs[1]['blocks'] == [[0, 1024], [1024, 2048]]
+    assert 'flat by construction' in d['strong_scaling_note'] and d['scaling'] == 'weak'
+    assert [l['blocks'][-1] for l in dry('--gpus', '8')['strong_scaling_legs']] == [[448, 512], [1792, 2048]]
+    for args in (('--gpus', '1'), ('--gpus', '8', '--total-pop', '512'), ('--gpus', '8', '--pop', '64'), ('--gpus', '8', '--strong-legs', 'off')):
+        assert dry(*args)['strong_scaling_legs'] == []
+
+
 def test_member_blocks_cover_population():
     from serl_amd import distributed as sd
     for pop in (1, 5, 50, 512, 2048):
@@ -238,6 +259,16 @@ def test_bench_starts_itself_for_n_gpus_or_says_why_not():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 1 and line['value'] > 0
+    assert 'strong_scaling_legs' not in line          # (--pop given: no legs)
+    # ... and the strong-scaling legs an N-GPU run appends (forced here on the one rank): BASELINE configs 4 and 5 through the same process group
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+                        '--master-port', str(29750 + os.getpid() % 2000), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '1',
+                        '--warmup', '0', '--no-cpu-baseline', '--strong-legs', 'on'], capture_output=True, text=True, timeout=550, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith('{')][-1])
+    legs = line['strong_scaling_legs']
+    assert [(l['config']['total_pop'], l['scaling']) for l in legs] == [(512, 'strong'), (2048, 'strong')]
+    assert all(l['value'] > 1e7 and l['rccl']['world_size'] == 1 for l in legs) and line['scaling'] == 'weak' and 'flat by construction' in line['strong_scaling_note']
 
 
 # ---- a whole generation sharded over two ranks (serl_amd.generation.evaluate_generation_sharded) --------------------------
