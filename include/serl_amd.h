@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SERL_ABI_VERSION 6
+#define SERL_ABI_VERSION 7
 
 enum serl_error {
   SERL_OK = 0,
@@ -213,6 +213,13 @@ int serl_ctx_load_build(serl_ctx *ctx, int slot, const serl_build_desc *build);
 
 /* One population evaluation: all episodes of the descriptor, one fused kernel launch per call. */
 int serl_rollout(serl_ctx *ctx, const serl_rollout_desc *desc, void *stream);
+/* ABI v7.  A mixed-fault population (fault mode per episode, /root/reference/envs/phlabenv.py:114-165: the builds be / jr / sa / se / cg share the
+ * nominal code on different tables, ice has code of its own) as ONE launch of ONE code object: `n` descriptors (2 .. 4), one per dynamics build,
+ * each exactly what serl_rollout would take (its own build_slot, episodes, outputs; concurrent_episodes is ignored).  Results are those of n
+ * separate serl_rollout calls, bit for bit.  Eligible: attitude task, hidden 32, code variants nominal / ice, kernel_hint AUTO, more than
+ * 2 x CUs episodes together; otherwise SERL_E_UNSUPPORTED and nothing was launched (the caller falls back to one serl_rollout per descriptor,
+ * side by side on streams of their own).  `descs` is an array of n descriptors, contiguous in HOST memory. */
+int serl_rollout_multi(serl_ctx *ctx, int32_t n, const serl_rollout_desc *descs, void *stream);
 
 /* Dynamics only (test / micro-benchmark entry): per episode initialize() followed by T calls of the
  * reference's step(cmd) -- cmds f64 [n_episodes][T][10] -> states f64 [n_episodes][T][12] (device). */

@@ -9,7 +9,7 @@ VP = ctypes.c_void_p
 LIB_PATH = os.environ.get('SERL_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libserl_amd.so')
 
 EXPORTS = ['serl_abi_version', 'serl_last_error', 'serl_param_count', 'serl_ctx_create', 'serl_ctx_destroy',
-           'serl_ctx_load_build', 'serl_rollout', 'serl_dyn_open_loop', 'serl_debug_profile', 'serl_last_rollout_ms', 'serl_ga_clone', 'serl_ga_crossover',
+           'serl_ctx_load_build', 'serl_rollout', 'serl_rollout_multi', 'serl_dyn_open_loop', 'serl_debug_profile', 'serl_last_rollout_ms', 'serl_ga_clone', 'serl_ga_crossover',
            'serl_ga_mutate', 'serl_ga_scaled_perturb', 'serl_abi_layout', 'serl_ga_sensitivity', 'serl_ga_novelty',
            'serl_replay_scatter', 'serl_env_state_dim', 'serl_env_action_dim',
            'serl_smoothness', 'serl_smoothness_work_size', 'serl_ga_distill', 'serl_host_sample_slots']
@@ -52,7 +52,7 @@ class ReplayJob(ctypes.Structure):
 
 # serl_rollout_desc.kernel_hint (enum serl_kernel_hint)
 KERNEL_HINTS = {None: 0, 'auto': 0, 'team': 1, 'wave': 2, 'half': 3, 'team2': 4, 'team4': 5}
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def expected_layout():
@@ -84,6 +84,7 @@ def lib():
     L.serl_ctx_destroy.argtypes = [VP]
     L.serl_ctx_load_build.argtypes = [VP, ctypes.c_int, ctypes.POINTER(BuildDesc)]
     L.serl_rollout.argtypes = [VP, ctypes.POINTER(RolloutDesc), VP]
+    L.serl_rollout_multi.argtypes = [VP, ctypes.c_int32, ctypes.POINTER(RolloutDesc), VP]
     L.serl_dyn_open_loop.argtypes = [VP, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, VP, VP, ctypes.c_int32, ctypes.c_int32, VP]
     L.serl_debug_profile.argtypes = [VP, ctypes.POINTER(ctypes.c_ulonglong)]
     L.serl_last_rollout_ms.argtypes = [VP, ctypes.POINTER(ctypes.c_float)]
@@ -114,6 +115,9 @@ def lib():
                            'library %s, binding %s' % (list(got)[:n], want))
     _lib = L
     return L
+
+
+E_UNSUPPORTED = -3      # enum serl_status SERL_E_UNSUPPORTED
 
 
 def check(rc, what):

@@ -32,6 +32,7 @@ SERL_DECL_WAVE(nominal) SERL_DECL_WAVE(ice) SERL_DECL_WAVE(cg_timed) SERL_DECL_W
   void serl_launch_dyn_team_##v(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
 SERL_DECL_TEAM(nominal) SERL_DECL_TEAM(ice) SERL_DECL_TEAM(cg_timed) SERL_DECL_TEAM(gust) SERL_DECL_TEAM(test)
 // ... with one forward pass over two actor wavefronts (rollout_teams2_<v>.hip: hidden > 64)
+#include "serl_mixed.h"
 #define SERL_DECL_TEAMS2(v) void serl_launch_rollout_teams2_##v(const RolloutArgs &a, int grid, hipStream_t stream);
 SERL_DECL_TEAMS2(nominal) SERL_DECL_TEAMS2(ice) SERL_DECL_TEAMS2(cg_timed) SERL_DECL_TEAMS2(gust) SERL_DECL_TEAMS2(test)
 
@@ -360,7 +361,8 @@ int serl_ctx_load_build(serl_ctx *c, int slot, const serl_build_desc *b)
 
 int serl_param_count(int S, int H, int L, int A) { return H * S + H + L * (H * H + 3 * H) + A * H + A; }
 
-int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
+// argument checks of serl_rollout / serl_rollout_multi; *hint_out = the resolved kernel hint
+static int serl_check_desc(serl_ctx *c, const serl_rollout_desc *d, int *hint_out)
 {
   if (!c || !d) return fail(SERL_E_INVALID, "serl_rollout: NULL argument");
   if (d->build_slot < 0 || d->build_slot >= SERL_MAX_SLOTS || !c->slots[d->build_slot].loaded)
@@ -387,6 +389,27 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   const int hint = d->lanes_per_wave > 0 ? SERL_KERNEL_AUTO : serl_resolve_hint(c, d->kernel_hint);
   if (d->hidden != 32 && (hint == SERL_KERNEL_TEAM4 || hint == SERL_KERNEL_HALF))
     return fail(SERL_E_UNSUPPORTED, "serl_rollout: kernel_hint TEAM4 / HALF needs hidden = 32 (other shapes: TEAM2, the actor wavefront runs the two episodes one after the other)");
+  *hint_out = hint;
+  return SERL_OK;
+}
+
+// RolloutArgs of one descriptor on its build's tables (what every launch path starts from)
+static void serl_fill_args(serl_ctx *c, const serl_rollout_desc *d, RolloutArgs &a)
+{
+  const BuildSlot &s = c->slots[d->build_slot];
+  memset(&a, 0, sizeof(a));
+  a.d = *d;
+  a.ro = s.blob; a.t3 = s.blob + s.n_ro; a.x0 = a.t3 + 46; a.dw0 = a.x0 + 19;
+  a.dyn_dt = s.dt;
+  a.jitter = c->env_jitter; a.jitter_sites = c->env_jitter_sites;
+  a.prof = nullptr;
+}
+
+int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
+{
+  int hint = SERL_KERNEL_AUTO;
+  { const int rc_ = serl_check_desc(c, d, &hint); if (rc_ != SERL_OK) return rc_; }
+  const bool general_env = d->env_config != SERL_ENV_ATTITUDE || d->incremental != 0;
   HIP_TRY(hipSetDevice(c->device));
   const BuildSlot &s = c->slots[d->build_slot];
   hipStream_t stream = (hipStream_t)stream_;
@@ -551,6 +574,67 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   HIP_TRY(hipGetLastError());
   if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
   c->timed = timed;
+  return SERL_OK;
+}
+
+// Several descriptors -- one per dynamics build of a mixed-fault population -- in ONE launch of one code object (rollout_team4_mixed.hip).
+// Eligible: 2 .. SERL_MIXED_MAX descriptors of the attitude task with the LDS-sized actor shape (hidden 32), code variants nominal / ice, automatic
+// kernel choice, more than 2 x CUs episodes together (the four-episodes-per-team size class).  Anything else returns SERL_E_UNSUPPORTED and the
+// caller launches the descriptors one by one (serl_rollout with concurrent_episodes, streams of their own).
+int serl_rollout_multi(serl_ctx *c, int32_t n, const serl_rollout_desc *descs, void *stream_)
+{
+  if (!c || !descs) return fail(SERL_E_INVALID, "serl_rollout_multi: NULL argument");
+  if (n < 2 || n > SERL_MIXED_MAX) return fail(SERL_E_UNSUPPORTED, "serl_rollout_multi: 2 .. 4 descriptors");
+  int together = 0;
+  for (int k = 0; k < n; ++k) {
+    const serl_rollout_desc *d = descs + k;
+    int hint = SERL_KERNEL_AUTO;
+    const int rc_ = serl_check_desc(c, d, &hint);
+    if (rc_ != SERL_OK) return rc_;
+    const int code = c->slots[d->build_slot].code;
+    if (d->env_config != SERL_ENV_ATTITUDE || d->incremental != 0 || d->hidden != 32 || d->num_layers > 3 || d->lanes_per_wave > 0 ||
+        hint != SERL_KERNEL_AUTO || (code != SERL_DYN_NOMINAL && code != SERL_DYN_ICE))
+      return fail(SERL_E_UNSUPPORTED, "serl_rollout_multi: attitude task, hidden 32, code variants nominal / ice, kernel_hint AUTO");
+    together += d->n_episodes;
+  }
+  if (together <= 2 * c->num_cus) return fail(SERL_E_UNSUPPORTED, "serl_rollout_multi: for more than 2 x CUs episodes (four per team)");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  SerlMixedArgs m;
+  memset(&m, 0, sizeof(m));
+  m.n = n;
+  const bool queue = together > 4 * c->num_cus;      // beyond four per CU: every part drains a work queue of its own on its share of the CUs
+  int wg = 0;
+  for (int k = 0; k < n; ++k) {
+    const serl_rollout_desc *d = descs + k;
+    RolloutArgs &a = m.a[k];
+    serl_fill_args(c, d, a);
+    a.lanes = 1;
+    a.block = 512;
+    int grid = (d->n_episodes + 3) / 4;
+    a.queue = nullptr; a.q0 = d->n_episodes;
+    if (queue) {
+      int share = (int)((long long)c->num_cus * d->n_episodes / together);
+      share = share < 1 ? 1 : share;
+      if (share * 4 < d->n_episodes) {
+        grid = share;
+        a.queue = serl_next_queue_counter(c);
+        a.q0 = 4 * grid;
+        HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(int32_t), stream));
+      }
+    }
+    m.first_wg[k] = wg;
+    m.code[k] = c->slots[d->build_slot].code;
+    // the lane-group kernels find their episodes at e0 + blockIdx.x * 4 + group: shift e0 (and the queue's first episode stays absolute)
+    a.e0 = -4 * wg; a.e_end = d->n_episodes;
+    wg += grid;
+  }
+  m.first_wg[n] = wg;
+  HIP_TRY(hipEventRecord(c->ev0, stream));
+  serl_launch_rollout_team4_mixed(m, wg, stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev1, stream));
+  c->timed = true;
   return SERL_OK;
 }
 

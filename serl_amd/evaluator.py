@@ -57,6 +57,7 @@ class RolloutEngine:
         # queues when it is created, and streams made back to back land on different ones (measured: profiles/r01_g_mixed.md)
         self._side = [torch.cuda.Stream(self.device) for _ in range(3)]
         self.last_kernel_ms = 0.0
+        self.num_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         # serl_rollout_desc.kernel_hint of rollouts that do not name one (None = chosen from the episode count); tests and
         # A/B measurements set it to compare the kernel families ('team', 'team2', 'team4', 'wave', 'half')
         self.kernel_hint = None
@@ -95,11 +96,12 @@ class RolloutEngine:
     # ------------------------------------------------------------------------------------------
     def rollout(self, weights, spec: NetSpec, member_of_episode, ref, *, build='h2000_v90', faults=None,
                 err0=None, tick0=None, action_noise=None, noise_row=None, sensor_noise=None, sensor_row=None, t_max=80.0, traces=False,
-                transitions=False, lanes_per_wave=0, sync=True, concurrent_episodes=0, env_config=0, incremental=False, kernel=None):
+                transitions=False, lanes_per_wave=0, sync=True, concurrent_episodes=0, env_config=0, incremental=False, kernel=None, launch=True):
         """Low-level: run len(member_of_episode) episodes.  weights f32 [M, >=P] (device or host),
         ref f64 [E, T, 3] or [T, 3] radians.  env_config / incremental: builds.env_config(name) (the attitude task by
         default; the per-episode tables keep their 3-column layouts, transitions have 2 S + A + 3 columns).
-        Returns dict of device tensors."""
+        Returns dict of device tensors.  launch=False: nothing is launched -- the prepared descriptor rides along as out['_desc'] for
+        rollout_multi (one launch for the descriptors of several builds)."""
         S_, A_ = builds.env_dims(env_config, incremental)
         if (spec.state_dim, spec.action_dim) != (S_, A_):
             raise ValueError('actor %d -> %d does not fit the env configuration (%d observations, %d actions)'
@@ -175,9 +177,12 @@ class RolloutEngine:
         if transitions:
             out['transitions'] = torch.zeros(E, T, 2 * spec.state_dim + spec.action_dim + 3, dtype=torch.float32, device=dev)
             d.transitions = out['transitions'].data_ptr()
+        out['_keep'] = keep
+        if not launch:
+            out['_desc'] = d
+            return out
         stream = torch.cuda.current_stream(dev).cuda_stream
         _capi.check(self.lib.serl_rollout(self.ctx, ctypes.byref(d), ctypes.c_void_p(stream)), 'serl_rollout')
-        out['_keep'] = keep
         if sync:
             ms = ctypes.c_float()
             _capi.check(self.lib.serl_last_rollout_ms(self.ctx, ctypes.byref(ms)), 'serl_last_rollout_ms')
@@ -187,6 +192,19 @@ class RolloutEngine:
                 raise RuntimeError('reference table too short: %d episodes were still running after %d steps'
                                    % (int(bad.sum()), T))
         return out
+
+    def rollout_multi(self, prepared):
+        """ONE launch of ONE code object for the descriptors of several dynamics builds (C ABI v7 serl_rollout_multi: a mixed-fault population,
+        envs/phlabenv.py:114-165).  `prepared`: the dicts rollout(..., launch=False) returned.  Returns True when the library launched them, False
+        when the combination is not eligible (SERL_E_UNSUPPORTED: nothing was launched; the caller launches them one by one)."""
+        n = len(prepared)
+        arr = (_capi.RolloutDesc * n)(*[p['_desc'] for p in prepared])
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.serl_rollout_multi(self.ctx, n, arr, ctypes.c_void_p(stream))
+        if rc == _capi.E_UNSUPPORTED:
+            return False
+        _capi.check(rc, 'serl_rollout_multi')
+        return True
 
     def dynamics_open_loop(self, cmds, build='h2000_v90', lanes_per_wave=0, kernel=None):
         """Dynamics only: cmds f64 [E, T, 10] -> states f64 [E, T, 12] (what the reference's raw
@@ -227,7 +245,7 @@ def _as_weights(actors, spec):
 def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, smooth_fitness=False,
                  spec: Optional[NetSpec] = None, engine: Optional[RolloutEngine] = None, traces=False,
                  transitions=False, err0=None, tick0=None, lanes_per_wave=0, need_smoothness=True,
-                 sensor_rng=None, concurrent=True) -> PopResult:
+                 sensor_rng=None, concurrent=True, fused='auto') -> PopResult:
     """Evaluate a whole population: `num_evals` episodes per member (agent.py:229-256).
 
     actors : sequence of Actor / GeneticAgent, or a packed f32 tensor [pop, P] (then pass `spec`)
@@ -243,6 +261,9 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
              does not reset the model clock, so in its sequential loop episode j of a process starts at
              tick = sum over earlier episodes of (steps + 1); only the time-switched builds (cg-shift, gust) care.
     concurrent : False = the per-build launches run one after the other (A/B switch)
+    fused      : several builds as ONE launch of one code object (C ABI v7 serl_rollout_multi).  'auto' (default): beyond 4 x CUs episodes, where
+                 it measured +3.7 % (6 144 episodes: 37.3 against 36.0 M env-steps/s; at 768 episodes 28.8 against 29.1 M: a launch per build side by
+                 side is as fast there -- profiles/r05_experiments.md section 9); True: whenever the library accepts the combination; False: never
     sensor_rng : modes 'noise' / 'gust' add the reference's sensor model to what step() returns; its randn draws
              come from this legacy generator (None = np.random, like the wrappers), one block of T + 1 steps per
              noisy episode in episode order, up front (builds.sensor_noise_table)
@@ -293,8 +314,8 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
     if many:
         ev0.record(cur)
     parts = []
-    for b, idx in groups.items():
-        idx = np.asarray(idx)
+
+    def one_build(b, idx, side, **kw):
         rows = [resolved[e][1] for e in idx]
         faults = np.array(rows, dtype=np.float64) if any(r != builds.NOMINAL_ROW for r in rows) else None
         whole = len(idx) == E
@@ -304,15 +325,28 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
             sn = np.stack([sensor[e] for e in noisy])
             pos = {e: j for j, e in enumerate(noisy)}
             sr = np.array([pos.get(e, -1) for e in idx], dtype=np.int32)
+        with torch.cuda.stream(side):
+            return engine.rollout(w, spec, moe[idx], (refs if (whole or len(refs) == 1) else refs[idx]) if generated else
+                                  (refs if (whole or refs.dim() == 2) else refs[torch.as_tensor(idx)]), build=b,
+                                  faults=faults, err0=None if err0 is None else err0[idx],
+                                  tick0=None if tick0 is None else tick0[idx], t_max=t_max, sensor_noise=sn, sensor_row=sr,
+                                  traces=want, transitions=transitions, lanes_per_wave=lanes_per_wave, env_config=env_cfg, incremental=incremental, **kw)
+
+    # Several builds of the attitude task with the LDS-sized actor shape: ONE launch of ONE code object (C ABI v7 serl_rollout_multi,
+    # rollout_team4_mixed.hip) -- two different code objects side by side cost 12 % (profiles/r04_experiments.md section 4).  The library says
+    # whether the combination is eligible; if not, nothing was launched and the launches below run side by side as before.
+    fused = False
+    if many and (fused is True or (fused == 'auto' and E > 4 * engine.num_cus)) and 2 <= len(groups) <= 4 and lanes_per_wave == 0 and env_cfg == 0 and not incremental and spec.hidden == 32:
+        prepared = [(np.asarray(idx), one_build(b, np.asarray(idx), cur, sync=False, launch=False)) for b, idx in groups.items()]
+        if engine.rollout_multi([o for _, o in prepared]):
+            fused = True
+            parts = [(idx, o, cur) for idx, o in prepared]
+    for b, idx in ([] if fused else groups.items()):
+        idx = np.asarray(idx)
+        whole = len(idx) == E
         side = engine.side_stream(len(parts)) if many else cur
         side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            o = engine.rollout(w, spec, moe[idx], (refs if (whole or len(refs) == 1) else refs[idx]) if generated else
-                               (refs if (whole or refs.dim() == 2) else refs[torch.as_tensor(idx)]), build=b,
-                               faults=faults, err0=None if err0 is None else err0[idx],
-                               tick0=None if tick0 is None else tick0[idx], t_max=t_max, sensor_noise=sn, sensor_row=sr,
-                               traces=want, transitions=transitions, lanes_per_wave=lanes_per_wave, sync=not (many or whole),
-                               concurrent_episodes=(E - len(idx)) if many else 0, env_config=env_cfg, incremental=incremental)
+        o = one_build(b, idx, side, sync=not (many or whole), concurrent_episodes=(E - len(idx)) if many else 0)
         if whole:      # (not waited for: the smoothness pass below is enqueued behind the kernel first)
             out = o
             break
