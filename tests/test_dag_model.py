@@ -155,6 +155,10 @@ def test_every_cross_wavefront_read_of_the_generated_team_code_is_covered_by_its
             if st:
                 assert int(st.group(3)) == b
                 stored += [(b, 2 * j) for j in range(int(st.group(1)), int(st.group(2)))] + [(b, 2 * j + 1) for j in range(int(st.group(1)), int(st.group(2)))]
+            sc = re.search(r'g_m\[CITW_MROW\((\d+)\)\]\[(\d+)\] = v\d+; g_m\[CITW_MROW\((\d+)\)\]\[(\d+)\] = 0\.0;', line)
+            if sc:      # (round 5) a guarded call made wave-uniformly: the result and its unused second slot stored by the wavefront itself
+                assert int(sc.group(1)) == b and int(sc.group(3)) == b and int(sc.group(4)) == int(sc.group(2)) + 1
+                stored += [(b, int(sc.group(2))), (b, int(sc.group(4)))]
             rs = re.search(r'citw_flag_raise\((\d+),', line)
             if rs:
                 fl = int(rs.group(1))

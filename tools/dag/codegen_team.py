@@ -75,6 +75,7 @@ LIBM_WAVE = {kv.split(':')[0]: int(kv.split(':')[1]) for kv in os.environ.get('C
 EARLY_FLAG = int(os.environ.get('CITW_TEAM_EARLY_FLAG', 2))             # 2: the first libm function group of a wavefront (sincos in front of tan) is announced by a flag of its own, g_flag[8 + q] -- except on the wavefront of the handed-over chain (1: there too -- with lane groups that produced NaNs in the first launch of a process, r03 sweeps 39 / 41, cause not found; 0: off)
 TAN_MERGE = int(os.environ.get('CITW_TEAM_TAN_MERGE', 1))               # 1: the tan lanes of a wavefront ride its sincos pass and divide behind it (no second body)
 TWO_PASS = int(os.environ.get('CITW_TEAM_TWO_PASS', 1))                 # 1: a helper computes what needs no foreign libm result before its first flag wait, node by node
+SCALAR_LIBM = int(os.environ.get('CITW_TEAM_SCALAR_LIBM', 1))          # 1: one or two individually guarded libm calls of a wavefront are made wave-uniformly under their guards' scalar branches (no LDS trip of argument and result)
 SPEC_1D = int(os.environ.get('CITW_TEAM_SPEC_1D', 1))                  # 1: ... and round 1's 1-D tables ride those lanes too (one episode per team; no helper pass behind the hint verification)
 SPEC = int(os.environ.get('CITW_TEAM_SPEC', 1))                        # 1: emit the merged descriptor row + the precomputed look-up lanes of wave 0 (citw_spec_pre / citw_spec_tail; compiled in with -DCITW_SPEC_LOOKUP=1)
 STAGE0 = int(os.environ.get('CITW_TEAM_STAGE0', 1))                    # 1: glue that depends on the command vector alone runs in the first of the six evaluations only (its look-up inputs / exchanged values keep their LDS slots)
@@ -847,6 +848,33 @@ class TeamGen(codegen.Gen):
                 keys = [self.libm_calls[j][0] for j in calls]
                 direct = (len(set(k_[0] for k_ in keys)) == 1 and keys[0][0] != 'pow' and not any(j in self.call_guard for j in calls)
                           and all(g.nodes[k_[1]][0] == 'in' and g.nodes[k_[1]][1] == 'X' for k_ in keys) and len(set(g.nodes[k_[1]][2] for k_ in keys)) == len(keys))
+                scalar = (SCALAR_LIBM and not direct and len(calls) <= 2 and all(j in self.call_guard for j in calls)
+                          and all(k_[0] in ('pow', 'exp', 'log10', 'log') for k_ in keys) and all(set(self.libm_calls[j][1]) == {'r0'} for j in calls))
+                if scalar:
+                    # Round 5: one or two calls, each under a wave-uniform guard of its own (the ISA atmosphere: the troposphere's power law OR the
+                    # stratosphere's exponential): made by the whole wavefront under the guard's scalar branch, on the argument it holds in registers --
+                    # no trip of the argument through LDS to "its" lane and of the result back (two round trips on the chain that hands the air-data
+                    # look-up input to wave 0).  Same function, same argument: the same bits; the results still go to g_m for the other wavefronts.
+                    for j in calls:
+                        (fn, arg, prm) = self.libm_calls[j][0]
+                        nd = self.libm_calls[j][1]['r0']
+                        gd = self.call_guard[j]
+                        call = {'pow': 'citw_pow(%s, %s)' % (self.ref(arg), hexf(prm))}.get(fn, '%s(%s)' % ({'atan': 'citw_atan'}.get(fn, fn), self.ref(arg)))
+                        B('  double v%d = 0.0;' % nd)
+                        B('  if (%s%s) { v%d = %s; }   /* (wave-uniform: the whole wavefront makes the call) */' % ('' if gd[1] else '!', self.ref(gd[0]), nd, call))
+                        emitted.add(nd)
+                    B('  if (CITW_LANE0) {')
+                    for j in calls:
+                        jl = self.calls_of[b].index(j)
+                        B('    g_m[%d][%d] = v%d; g_m[%d][%d] = 0.0;' % (b, 2 * jl, self.libm_calls[j][1]['r0'], b, 2 * jl + 1))
+                    B('  }')
+                    B('  CITW_WAVE_FENCE();')
+                    made.update(calls)
+                    if raise_flag:
+                        B('  citw_flag_raise(%d, %s);' % (b, SEQ))
+                        B('  CITW_LIBM_PRIO(0);')
+                        B('  __builtin_amdgcn_sched_barrier(0);     /* nothing of what follows may be scheduled in front of the hand-over */')
+                    return
                 if direct:
                     # every argument IS a state: lane i of XL holds state i (the ODE5 combination this wavefront has just made), so the
                     # lanes of those states make the calls at once -- no trip through g_xs and the argument slots in front of the chain
