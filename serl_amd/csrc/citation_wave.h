@@ -447,6 +447,9 @@ static __device__ __forceinline__ double citw_u2d(unsigned long long u) { return
 // IS the result of the full count; if any lane of the wavefront fails the test (ballot) the wavefront runs the full count,
 // which also repairs the slot.  Slots start at 0 (staged by the kernels), any value is re-verified, NaN inputs fail every
 // compare and fall back to the count (idx 0, as before).
+// (round 5) every write that CHANGES an interval index counts g_smiss up: the lane-group kernels' wavefronts keep the interval-dependent half of
+// their look-up lanes in registers across evaluations (CitwPassCache below) and recompute it when the count has moved
+static __device__ __forceinline__ void citw_sidx_changed() { atomicAdd(&g_smiss, 1u); }
 template <int MAXN, int COUNT, int SBASE>
 static __device__ __forceinline__ void citw_search_pass(const int wv, const CitwSearch *S, int ln);
 // COUNT searches of one round, one per lane of the episode's lane group, in ceil(COUNT / CITW_GROUP_LANES) passes
@@ -552,8 +555,10 @@ static __device__ __forceinline__ void citw_search_pass(const int wv, const Citw
   if (__builtin_expect(__ballot(valid && !ok) != 0ULL, 0)) {
     const int idx = citw_search_count<MAXN>(x, n, u);
     if (valid) *slot = idx;
+    if (valid && idx != stored) citw_sidx_changed();
   } else if (valid && h != stored) {
     *slot = h;
+    citw_sidx_changed();
   }
 #else
   const int idx = citw_search_count<MAXN>(x, n, u);
@@ -729,6 +734,106 @@ static __device__ __forceinline__ void citw_lookup1d_pass(const int wv, const Ci
   r = r / (x1 - x0);
   r = r * (u - x0);
   out[wv][d.out] = r + y0;
+}
+
+// ---- The passes of the LANE-GROUP kernels with their interval-dependent half kept across evaluations (round 5; two / four episodes per team).
+// A helper wavefront runs ONE pass of a round -- lane l of a lane group always the same search or table of its episode -- and a pass is three
+// dependent LDS round trips (descriptor -> stored interval -> breakpoints / corners) and, for a table, two of its three divisions before the
+// inputs even matter.  None of that changes while the stored intervals do not (4 of 2 400 evaluations move one).  CitwPassCache holds one search
+// pass and one table pass of THIS wavefront: interval ends; x0, both x-direction quotients, two corners, y0, dy (a 1-D table: x0, its quotient,
+// y0).  The search lanes verify their hints against the cached ends (one LDS round trip: the input); a miss runs the plain pass -- which rewrites
+// g_sidx and counts g_smiss up -- and refills.  The table lanes read g_smiss with their inputs (every search flag of the round has been waited
+// for by then) and refill when it has moved since they were filled.  Same operations on the same operands in the same order as the plain passes.
+#ifndef CITW_PC_SEARCH
+#define CITW_PC_SEARCH 1      // 0: only the table passes are cached (five registers less per wavefront)
+#endif
+struct CitwPassCache {
+  double sxl, sxh; int sq;                       // search lane: ends of the stored interval; n | in << 8 | h << 16
+  double x0, sa, z00, sb, z01, y0, dy; int tq;   // table lane (as CitwSpec); tq: in0 | in1 << 8 | out << 16
+  unsigned epoch;                                // g_smiss when the table lane was filled
+  bool s_valid, t_valid;
+};
+static __device__ CitwPassCache citw_no_pass_cache;      // what the default arguments bind (never touched: HAVE_PC is false there)
+
+template <int MAXN, int COUNT, int PART, int NPARTS, int SBASE = 0>
+static __device__ __forceinline__ void citw_search_part_c(const int wv, const CitwSearch *S, int lane, const bool HAVE_PC, CitwPassCache &c)
+{
+  if (!HAVE_PC || !CITW_PC_SEARCH) { citw_search_part<MAXN, COUNT, PART, NPARTS, SBASE>(wv, S, lane); return; }
+  static_assert(PART * CITW_GROUP_LANES < COUNT && (PART + NPARTS) * CITW_GROUP_LANES >= COUNT, "one pass per part");
+  const int ln = lane + PART * CITW_GROUP_LANES;
+  const bool valid = ln < COUNT;
+  if (c.s_valid) {
+    const double u = g_in[wv][(c.sq >> 8) & 255];
+    const bool ok = citw_hint_ok((c.sq >> 16) & 255, c.sq & 255, c.sxl, c.sxh, u);
+    if (__builtin_expect(__ballot(valid && !ok) == 0ULL, 1)) return;      // every stored interval still holds: g_sidx is right as it is
+  }
+  citw_search_pass<MAXN, COUNT, SBASE>(wv, S, ln);       // first use, or an input left its interval: the plain pass repairs the slots (and counts g_smiss up)
+  {
+    const int lc = valid ? ln : 0;
+    const CitwSearch d = S[lc];
+    const int n = d.n;
+    int h = g_sidx[wv][SBASE + lc];                        // (this lane's own slot: what it has just stored or confirmed)
+    h = h < 0 ? 0 : h; h = h > n - 2 ? n - 2 : h;
+    const double *x = g_bp[d.row];
+    c.sxl = x[h]; c.sxh = x[h + 1];
+    c.sq = n | (int)d.in << 8 | h << 16;
+    c.s_valid = true;
+  }
+  CITW_WAVE_FENCE();
+}
+
+template <int COUNT, int PART, int NPARTS, typename OUT>
+static __device__ __forceinline__ void citw_lookup2d_part_c(const int wv, const CitwLookup *L, OUT &out, int lane, const bool HAVE_PC, CitwPassCache &c)
+{
+  if (!HAVE_PC) { citw_lookup2d_part<COUNT, PART, NPARTS>(wv, L, out, lane); return; }
+  static_assert(PART * CITW_GROUP_LANES < COUNT && (PART + NPARTS) * CITW_GROUP_LANES >= COUNT, "one pass per part");
+  const unsigned ep = g_smiss;
+  if (!c.t_valid || c.epoch != ep) {
+    const CitwLookup d = L[lane + PART * CITW_GROUP_LANES];
+    const int ix = g_sidx[wv][d.sx], iy = g_sidx[wv][d.sy];
+    const double *xr = g_ro + d.xrw, *xc = g_ro + d.xcw, *z = g_ro + d.zw;
+    const int nr = d.nr;
+    const double x0 = xr[ix], x1 = xr[ix + 1];
+    const double dx = x1 - x0;
+    const double z00 = z[ix + nr * iy], z10 = z[ix + 1 + nr * iy];
+    const double z01 = z[ix + nr * (iy + 1)], z11 = z[ix + 1 + nr * (iy + 1)];
+    double a = z10 - z00; a = a / dx;
+    double b = z11 - z01; b = b / dx;
+    const double y0 = xc[iy];
+    c.x0 = x0; c.sa = a; c.z00 = z00; c.sb = b; c.z01 = z01; c.y0 = y0; c.dy = xc[iy + 1] - y0;
+    c.tq = (int)d.in0 | (int)d.in1 << 8 | (int)d.out << 16;
+    c.epoch = ep; c.t_valid = true;
+  }
+  const double u0 = g_in[wv][c.tq & 255], u1 = g_in[wv][(c.tq >> 8) & 255];
+  const double wx = u0 - c.x0;
+  double a = c.sa * wx; a = a + c.z00;
+  double b = c.sb * wx; b = b + c.z01;
+  double r = b - a; r = r / c.dy; r = r * (u1 - c.y0);
+  out[wv][(c.tq >> 16) & 255] = r + a;
+  CITW_WAVE_FENCE();
+}
+
+template <int COUNT, int PART, int NPARTS, typename OUT>
+static __device__ __forceinline__ void citw_lookup1d_part_c(const int wv, const CitwLookup *L, OUT &out, int lane, const bool HAVE_PC, CitwPassCache &c)
+{
+  if (!HAVE_PC) { citw_lookup1d_part<COUNT, PART, NPARTS>(wv, L, out, lane); return; }
+  static_assert(PART * CITW_GROUP_LANES < COUNT && (PART + NPARTS) * CITW_GROUP_LANES >= COUNT, "one pass per part");
+  const unsigned ep = g_smiss;
+  if (!c.t_valid || c.epoch != ep) {
+    const CitwLookup d = L[lane + PART * CITW_GROUP_LANES];
+    const int i = g_sidx[wv][d.sx];
+    const double *x = g_ro + d.xrw, *y = g_ro + d.zw;
+    const double x0 = x[i], x1 = x[i + 1], y0 = y[i], y1 = y[i + 1];
+    double r = y1 - y0;
+    r = r / (x1 - x0);
+    c.x0 = x0; c.sa = r; c.z00 = y0;
+    c.tq = (int)d.in0 | (int)d.out << 16;
+    c.epoch = ep; c.t_valid = true;
+  }
+  const double u = g_in[wv][c.tq & 255];
+  double r = c.sa * (u - c.x0);
+  out[wv][(c.tq >> 16) & 255] = r + c.z00;
+  CITW_WAVE_FENCE();
 }
 
 // (citw_div_const -- x / c for a literal c in four instructions -- lives in citation_libm.h, free of LDS declarations, so that the device unit

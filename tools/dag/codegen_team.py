@@ -1062,7 +1062,7 @@ class TeamGen(codegen.Gen):
                     ns = n_search(R)
                     B('#if CITW_SEARCH_SHARE(%d) > 1   /* several episodes per team: the search passes are shared with waves 2 (and 4) */' % ns)
                     B('  citw_iflag_raise(7, %s);   /* the look-up inputs are in g_in[0] */' % SEQ)
-                    B('  citw_search_part<%d, %d, 0, CITW_SEARCH_SHARE(%d), %d>(wv, S[%d], lane);' % (R['maxn'], ns, ns, R['sbase'], R['tidx']))
+                    B('  citw_search_part_c<%d, %d, 0, CITW_SEARCH_SHARE(%d), %d>(wv, S[%d], lane, HAVE_PC, PC);' % (R['maxn'], ns, ns, R['sbase'], R['tidx']))
                     B('  citw_iflag_raise(0, %s);' % SEQ)
                     B('  citw_iflag_wait(%d, %s);' % (SEARCH_WAVES[0], SEQ))
                     B('#if CITW_SEARCH_SHARE(%d) > 2' % ns)
@@ -1077,7 +1077,7 @@ class TeamGen(codegen.Gen):
                 if r == 0:
                     B('  %s;' % TM(6))
                 if R['L2'] and r == 0 and self.l2_helpers:
-                    B('  citw_lookup2d_part<%d, 0, CITW_L2_SHARE>(wv, L[%d][0], g_out%d, lane);   /* (lane groups: waves %s take the other passes) */' % (len(R['L2']), R['tidx'], R['oarr'], self.l2_helpers))
+                    B('  citw_lookup2d_part_c<%d, 0, CITW_L2_SHARE>(wv, L[%d][0], g_out%d, lane, HAVE_PC, PC);   /* (lane groups: waves %s take the other passes) */' % (len(R['L2']), R['tidx'], R['oarr'], self.l2_helpers))
                 elif R['L2']:
                     B('  citw_lookup2d<%d>(%s, L[%d][0], g_out%d, lane);' % (len(R['L2']), row, R['tidx'], R['oarr']))
                 if r == 0:
@@ -1089,7 +1089,7 @@ class TeamGen(codegen.Gen):
                 if sp is not None:
                     B('#endif')
 
-            B('static __device__ CITW_EVAL_INLINE double citw_%s_team_eval_w%d(const int stage, const double T, const unsigned TICK, const unsigned FSEQ, const double XL, const bool HAVE_K = false, const CitwKRegs &KR = citw_no_kregs, const bool HAVE_SC = false, CitwSpecCache &SC = citw_no_spec_cache)' % (V, b))
+            B('static __device__ CITW_EVAL_INLINE double citw_%s_team_eval_w%d(const int stage, const double T, const unsigned TICK, const unsigned FSEQ, const double XL, const bool HAVE_K = false, const CitwKRegs &KR = citw_no_kregs, const bool HAVE_SC = false, CitwSpecCache &SC = citw_no_spec_cache, const bool HAVE_PC = false, CitwPassCache &PC = citw_no_pass_cache)' % (V, b))
             B('{')
             B('  const CitwSearch (*S)[64] = g_S; const CitwLookup (*L)[2][64] = g_L;')
             B('  const bool major = stage == 0;')
@@ -1208,7 +1208,7 @@ class TeamGen(codegen.Gen):
                 nsq = n_search(self.rounds[0])
                 B('#if CITW_SEARCH_SHARE(%d) > %d   /* several episodes per team: search pass %d, beside wave 0 */' % (nsq, kq, kq))
                 B('  citw_iflag_wait(7, %s);' % SEQ)
-                B('  citw_search_part<%d, %d, %d, CITW_SEARCH_SHARE(%d), %d>(0, S[0], lane);' % (self.rounds[0]['maxn'], nsq, kq, nsq, self.rounds[0]['sbase']))
+                B('  citw_search_part_c<%d, %d, %d, CITW_SEARCH_SHARE(%d), %d>(0, S[0], lane, HAVE_PC, PC);' % (self.rounds[0]['maxn'], nsq, kq, nsq, self.rounds[0]['sbase']))
                 B('  citw_iflag_raise(%d, %s);' % (bb, SEQ))
                 B('#endif')
             B('  /* ---- share of this wave in the look-up independent glue */')
@@ -1269,13 +1269,13 @@ class TeamGen(codegen.Gen):
                 k = self.l2_helpers.index(b) + 1
                 B('#if CITW_L2_SHARE > %d   /* several episodes per team: pass %d (of every CITW_L2_SHARE) of round 1\'s 2-D interpolation, beside wave 0 */' % (k, k))
                 wait_searches(b)
-                B('  citw_lookup2d_part<%d, %d, CITW_L2_SHARE>(0, L[0][0], g_out0, lane);' % (len(self.rounds[0]['L2']), k))
+                B('  citw_lookup2d_part_c<%d, %d, CITW_L2_SHARE>(0, L[0][0], g_out0, lane, HAVE_PC, PC);' % (len(self.rounds[0]['L2']), k))
                 B('#endif')
             if b == SHARE_1D_WAVE and self.h1d is not None and self.l2_helpers and SHARE_1D:
                 n1 = n_l1(self.rounds[0])
                 B('#if CITW_L1_SHARE(%d) > 1   /* 16 lanes per episode: the second pass of the 1-D interpolation, beside wave 1 */' % n1)
                 wait_searches(b)
-                B('  citw_lookup1d_part<%d, 1, 2>(0, L[0][1], g_out0, lane);' % n1)
+                B('  citw_lookup1d_part_c<%d, 1, 2>(0, L[0][1], g_out0, lane, HAVE_PC, PC);' % n1)
                 B('#endif')
             if b != 0 and b == self.h1d:
                 if SPEC_1D and self.spec is not None:
@@ -1285,7 +1285,7 @@ class TeamGen(codegen.Gen):
                 wait_searches(b)
                 if self.l2_helpers and SHARE_1D:
                     n1 = n_l1(self.rounds[0])
-                    B('  citw_lookup1d_part<%d, 0, CITW_L1_SHARE(%d)>(0, L[0][1], g_out0, lane);   /* (16 lanes per episode: wave 3 takes the second pass) */' % (n1, n1))
+                    B('  citw_lookup1d_part_c<%d, 0, CITW_L1_SHARE(%d)>(0, L[0][1], g_out0, lane, HAVE_PC, PC);   /* (16 lanes per episode: wave 3 takes the second pass) */' % (n1, n1))
                 else:
                     B('  citw_lookup1d<%d>(0, L[0][1], g_out0, lane);' % n_l1(self.rounds[0]))
                 if SPEC_1D and self.spec is not None:
@@ -1396,7 +1396,7 @@ class TeamGen(codegen.Gen):
             text = re.sub(r'\bg_m\[(\d+)\]', r'g_m[CITW_MROW(\1)]', text)
             text = re.sub(r'\bg_x\[(\d+)\]', r'g_x[CITW_XOFF + \1]', text)
             text = re.sub(r'\bg_y\[(\d+)\]', r'g_y[CITW_YOFF + \1]', text)
-            text = re.sub(r'\b(citw_spec_pre<[^>]*>|citw_spec_tail<[^>]*>|citw_search<[^>]*>|citw_search_part<[^>]*>|citw_lookup2d<\d+>|citw_lookup2d_part<[^>]*>|citw_lookup1d<\d+>|citw_lookup1d_part<[^>]*>)\(0, ', r'\1(CITW_TROW, ', text)
+            text = re.sub(r'\b(citw_spec_pre<[^>]*>|citw_spec_tail<[^>]*>|citw_search<[^>]*>|citw_search_part<[^>]*>|citw_lookup2d<\d+>|citw_lookup2d_part<[^>]*>|citw_lookup1d<\d+>|citw_lookup1d_part<[^>]*>|citw_search_part_c<[^>]*>|citw_lookup2d_part_c<[^>]*>|citw_lookup1d_part_c<[^>]*>)\(0, ', r'\1(CITW_TROW, ', text)
             text = text.replace('const int lane = threadIdx.x & 63;', 'const int lane = CITW_LANE;')
             if FMA:
                 text = self.fuse_fma(text)
@@ -1408,11 +1408,11 @@ class TeamGen(codegen.Gen):
         for b in range(K - 1, -1, -1):
             P(function(b))
         P('/* wave-uniform dispatch: each wavefront of the team executes exactly one of the parts and its two barriers */')
-        P('static __device__ __forceinline__ double citw_%s_team_eval(const int wave, const int stage, const double T, const unsigned TICK, const unsigned FSEQ, const double XL, const bool HAVE_K = false, const CitwKRegs &KR = citw_no_kregs, const bool HAVE_SC = false, CitwSpecCache &SC = citw_no_spec_cache)' % V)
+        P('static __device__ __forceinline__ double citw_%s_team_eval(const int wave, const int stage, const double T, const unsigned TICK, const unsigned FSEQ, const double XL, const bool HAVE_K = false, const CitwKRegs &KR = citw_no_kregs, const bool HAVE_SC = false, CitwSpecCache &SC = citw_no_spec_cache, const bool HAVE_PC = false, CitwPassCache &PC = citw_no_pass_cache)' % V)
         P('{')
         for b in range(K - 1):
-            P('  if (wave == %d) return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ, XL, HAVE_K, KR, HAVE_SC, SC);' % (b, V, b))
-        P('  return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ, XL, HAVE_K, KR, HAVE_SC, SC);' % (V, K - 1))
+            P('  if (wave == %d) return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ, XL, HAVE_K, KR, HAVE_SC, SC, HAVE_PC, PC);' % (b, V, b))
+        P('  return citw_%s_team_eval_w%d(stage, T, TICK, FSEQ, XL, HAVE_K, KR, HAVE_SC, SC, HAVE_PC, PC);' % (V, K - 1))
         P('}')
         if KREGS:
             nk = max(1, max(len(v) for v in self.klit.values()))
