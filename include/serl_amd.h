@@ -218,7 +218,9 @@ int serl_rollout(serl_ctx *ctx, const serl_rollout_desc *desc, void *stream);
  * each exactly what serl_rollout would take (its own build_slot, episodes, outputs; concurrent_episodes is ignored).  Results are those of n
  * separate serl_rollout calls, bit for bit.  Eligible: attitude task, hidden 32, code variants nominal / ice, kernel_hint AUTO, more than
  * 2 x CUs episodes together; otherwise SERL_E_UNSUPPORTED and nothing was launched (the caller falls back to one serl_rollout per descriptor,
- * side by side on streams of their own).  `descs` is an array of n descriptors, contiguous in HOST memory. */
+ * side by side on streams of their own).  `descs` is an array of n descriptors, contiguous in HOST memory.  The launch places its workgroups so that
+ * CUs which share an instruction cache run the same code variant (SERL_MIXED_PLACE=0|1|2, read by serl_ctx_create, selects the placement for A/B;
+ * results do not depend on it). */
 int serl_rollout_multi(serl_ctx *ctx, int32_t n, const serl_rollout_desc *descs, void *stream);
 
 /* Dynamics only (test / micro-benchmark entry): per episode initialize() followed by T calls of the

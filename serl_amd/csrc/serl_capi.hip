@@ -315,6 +315,7 @@ int serl_ctx_create(int device, serl_ctx **out)
     c->env_waves_per_block = (e = getenv("SERL_WAVES_PER_BLOCK")) ? atoi(e) : -1;
     c->env_profile = getenv("SERL_PROFILE") != nullptr;
     c->env_split_actor = (e = getenv("SERL_SPLIT_ACTOR")) ? atoi(e) : 0;
+    c->env_mixed_place = (e = getenv("SERL_MIXED_PLACE")) ? atoi(e) : SERL_MIXED_PLACE_DEFAULT;
     c->env_jitter = (e = getenv("SERL_JITTER_SEED")) ? (unsigned)strtoul(e, nullptr, 0) : 0u;
     c->env_jitter_sites = (e = getenv("SERL_JITTER_SITES")) ? (unsigned)strtoul(e, nullptr, 0) : ~0u;
   }
@@ -334,6 +335,7 @@ int serl_ctx_destroy(serl_ctx *c)
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->prof) (void)hipFree(c->prof);
   if (c->queue) (void)hipFree(c->queue);
+  if (c->mixed_state) (void)hipFree(c->mixed_state);
   delete c;
   return SERL_OK;
 }
@@ -603,6 +605,13 @@ int serl_rollout_multi(serl_ctx *c, int32_t n, const serl_rollout_desc *descs, v
   SerlMixedArgs m;
   memset(&m, 0, sizeof(m));
   m.n = n;
+  m.place = c->env_mixed_place;
+  if (m.place != 0) {
+    if (!c->mixed_state) HIP_TRY(hipMalloc((void **)&c->mixed_state, SERL_MIXED_STATES * SERL_MIXED_STATE * sizeof(int32_t)));
+    m.state = c->mixed_state + (size_t)c->mixed_state_next * SERL_MIXED_STATE;
+    c->mixed_state_next = (c->mixed_state_next + 1) % SERL_MIXED_STATES;
+    HIP_TRY(hipMemsetAsync(m.state, 0, SERL_MIXED_STATE * sizeof(int32_t), stream));
+  }
   const bool queue = together > 4 * c->num_cus;      // beyond four per CU: every part drains a work queue of its own on its share of the CUs
   int wg = 0;
   for (int k = 0; k < n; ++k) {

@@ -7,6 +7,8 @@
 
 #define SERL_MAX_SLOTS 16
 #define SERL_QUEUE_COUNTERS 64
+#define SERL_MIXED_PLACE_DEFAULT 2
+#define SERL_MIXED_STATES 8             // placement states of serl_rollout_multi launches in flight (a ring, like the queue counters)
 
 int serl_fail(int code, const std::string &msg);      // records the thread-local message of serl_last_error()
 #define HIP_TRY(expr)                                                                           \
@@ -34,6 +36,9 @@ struct serl_ctx {
   int env_split_actor = 0;              // SERL_SPLIT_ACTOR=1: streamed actors of one-episode teams (hidden > 64) on TWO actor wavefronts that share the forward pass
                                         // (rollout_teams2_<v>.hip; measured slower than one wavefront with the specialised forward: profiles/r04_experiments.md)
   unsigned env_jitter_sites = ~0u;      // SERL_JITTER_SITES: classes of sites that pause (citation_wave.h; all by default)
+  int env_mixed_place = SERL_MIXED_PLACE_DEFAULT;      // SERL_MIXED_PLACE: how serl_rollout_multi places the parts' workgroups (serl_mixed.h)
+  int32_t *mixed_state = nullptr;       // device [SERL_MIXED_STATES][SERL_MIXED_STATE]
+  int mixed_state_next = 0;
   unsigned env_jitter = 0;              // SERL_JITTER_SEED: seed of the hand-over stress builds' pauses (libserl_amd_jitter.so; the product ignores it)
   BuildSlot slots[SERL_MAX_SLOTS];
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

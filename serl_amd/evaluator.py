@@ -58,6 +58,7 @@ class RolloutEngine:
         self._side = [torch.cuda.Stream(self.device) for _ in range(3)]
         self.last_kernel_ms = 0.0
         self.num_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        self.multi_launches = 0          # serl_rollout_multi launches made (a mixed sweep as one launch of one code object)
         # serl_rollout_desc.kernel_hint of rollouts that do not name one (None = chosen from the episode count); tests and
         # A/B measurements set it to compare the kernel families ('team', 'team2', 'team4', 'wave', 'half')
         self.kernel_hint = None
@@ -204,6 +205,7 @@ class RolloutEngine:
         if rc == _capi.E_UNSUPPORTED:
             return False
         _capi.check(rc, 'serl_rollout_multi')
+        self.multi_launches += 1
         return True
 
     def dynamics_open_loop(self, cmds, build='h2000_v90', lanes_per_wave=0, kernel=None):
@@ -261,9 +263,10 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
              does not reset the model clock, so in its sequential loop episode j of a process starts at
              tick = sum over earlier episodes of (steps + 1); only the time-switched builds (cg-shift, gust) care.
     concurrent : False = the per-build launches run one after the other (A/B switch)
-    fused      : several builds as ONE launch of one code object (C ABI v7 serl_rollout_multi).  'auto' (default): beyond 4 x CUs episodes, where
-                 it measured +3.7 % (6 144 episodes: 37.3 against 36.0 M env-steps/s; at 768 episodes 28.8 against 29.1 M: a launch per build side by
-                 side is as fast there -- profiles/r05_experiments.md section 9); True: whenever the library accepts the combination; False: never
+    fused      : several builds as ONE launch of one code object (C ABI v7 serl_rollout_multi), its workgroups placed so that CUs which share an
+                 instruction cache run the same code variant.  'auto' (default) and True: whenever the library accepts the combination (more than
+                 2 x CUs episodes, attitude task, hidden 32, nominal / ice code): 768 episodes 33.8 against 30.4 M env-steps/s for a launch per build
+                 side by side, 6 144 episodes 40.0 against 36.4 M (profiles/r05_experiments.md sections 9, 11); False: never
     sensor_rng : modes 'noise' / 'gust' add the reference's sensor model to what step() returns; its randn draws
              come from this legacy generator (None = np.random, like the wrappers), one block of T + 1 steps per
              noisy episode in episode order, up front (builds.sensor_noise_table)
@@ -333,15 +336,15 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
                                   traces=want, transitions=transitions, lanes_per_wave=lanes_per_wave, env_config=env_cfg, incremental=incremental, **kw)
 
     # Several builds of the attitude task with the LDS-sized actor shape: ONE launch of ONE code object (C ABI v7 serl_rollout_multi,
-    # rollout_team4_mixed.hip) -- two different code objects side by side cost 12 % (profiles/r04_experiments.md section 4).  The library says
+    # rollout_team4_mixed.hip), which can place its workgroups: two code variants on CUs that share an instruction cache cost 12 %.  The library says
     # whether the combination is eligible; if not, nothing was launched and the launches below run side by side as before.
-    fused = False
-    if many and (fused is True or (fused == 'auto' and E > 4 * engine.num_cus)) and 2 <= len(groups) <= 4 and lanes_per_wave == 0 and env_cfg == 0 and not incremental and spec.hidden == 32:
+    use_multi = False
+    if many and (fused is True or (fused == 'auto' and E > 2 * engine.num_cus)) and 2 <= len(groups) <= 4 and lanes_per_wave == 0 and env_cfg == 0 and not incremental and spec.hidden == 32:
         prepared = [(np.asarray(idx), one_build(b, np.asarray(idx), cur, sync=False, launch=False)) for b, idx in groups.items()]
         if engine.rollout_multi([o for _, o in prepared]):
-            fused = True
+            use_multi = True
             parts = [(idx, o, cur) for idx, o in prepared]
-    for b, idx in ([] if fused else groups.items()):
+    for b, idx in ([] if use_multi else groups.items()):
         idx = np.asarray(idx)
         whole = len(idx) == E
         side = engine.side_stream(len(parts)) if many else cur

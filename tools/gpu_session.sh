@@ -8,6 +8,7 @@
 #   bench            the driver's command (bench.py, defaults)
 #   bench:<args>     bench.py with the given arguments (commas for spaces), e.g. bench:--workload,serl10,--no-cpu-baseline
 #   pmc              the SQ issue counters + FETCH / WRITE sizes of one evaluation (separate passes, MI355X_MICROARCH.md)
+#   icache:<args>    instruction-cache counters (SQC_ICACHE_REQ / HITS / MISSES / MISSES_DUPLICATE, SQ_IFETCH) of one evaluation of bench.py <args>
 #   profile          tools/profile_round.sh <tag> (the round's whole profile series)
 #   py:<script.py>   any script of the repo
 TAG=$1; shift
@@ -42,6 +43,12 @@ for STEP in "$@"; do
        timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES -d $O/pmc_sq -o ps -- $P1 > $O/pmc_sq.log 2>&1)
       for k in fetch write sq; do python tools/pmc_summary.py $O/pmc_$k > $O/pmc_$k.json 2>> $O/err.txt; rm -rf $O/pmc_$k; done
       cat $O/pmc_sq.json | cut -c1-600 ;;
+    icache:*)
+      A=$(echo ${STEP#icache:} | tr ',' ' '); N=$(echo ${STEP#icache:} | tr -c 'a-zA-Z0-9' '_')
+      (cd /tmp && export TMPDIR=/tmp
+       timeout 600 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU -d $O/pmc_ic$N -o pi -- python $R/bench.py $A --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_ic$N.log 2>&1)
+      python tools/pmc_summary.py $O/pmc_ic$N > $O/pmc_ic$N.json 2>> $O/err.txt; rm -rf $O/pmc_ic$N
+      tr -d '\n' < $O/pmc_ic$N.json | cut -c1-500; echo ;;
     profile)
       bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1 ;;
     py:*)

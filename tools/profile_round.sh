@@ -18,8 +18,9 @@ timeout 600 $B --workload serl10 --pop 128 --steps 3 --warmup 1 --no-cpu-baselin
 timeout 600 $B --pop 64 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_pop64.json 2> $O/bench_pop64.err
 timeout 600 $B --pop 128 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_pop128.json 2> $O/bench_pop128.err     # 384 episodes: two per team
 timeout 600 $B --pop 341 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_pop341.json 2> $O/bench_pop341.err     # 1 023 episodes: four per team
-timeout 600 $B --workload mixed --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_mixed.json 2> $O/bench_mixed.err
-timeout 900 $B --workload mixed --total-pop 2048 --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_mixed_total2048.json 2> $O/bench_mixed_total2048.err   # BASELINE config 5 on one GPU: 6 144 episodes, queue launches side by side
+timeout 600 $B --workload mixed --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_mixed.json 2> $O/bench_mixed.err                 # 768 episodes, three builds: ONE launch of one code object, variants placed by CU pair
+timeout 600 $B --workload mixed --no-fused --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_mixed_nofused.json 2> $O/bench_mixed_nofused.err   # ... against a launch per build side by side
+timeout 900 $B --workload mixed --total-pop 2048 --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_mixed_total2048.json 2> $O/bench_mixed_total2048.err   # BASELINE config 5 on one GPU: 6 144 episodes through the parts' work queues
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 $R/bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_rccl1.json 2> $O/bench_rccl1.err
 (cd $R && timeout 300 python tools/bench_refill.py > $O/refill.json 2> $O/refill.err)
 CMD="$B --steps 3 --warmup 1 --no-cpu-baseline"
