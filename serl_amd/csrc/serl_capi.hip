@@ -336,6 +336,7 @@ int serl_ctx_destroy(serl_ctx *c)
   if (c->prof) (void)hipFree(c->prof);
   if (c->queue) (void)hipFree(c->queue);
   if (c->mixed_state) (void)hipFree(c->mixed_state);
+  for (auto &e : c->mixed_ev) if (e) (void)hipEventDestroy(e);
   delete c;
   return SERL_OK;
 }
@@ -606,10 +607,15 @@ int serl_rollout_multi(serl_ctx *c, int32_t n, const serl_rollout_desc *descs, v
   memset(&m, 0, sizeof(m));
   m.n = n;
   m.place = c->env_mixed_place;
+  int state_slot = -1;
   if (m.place != 0) {
     if (!c->mixed_state) HIP_TRY(hipMalloc((void **)&c->mixed_state, SERL_MIXED_STATES * SERL_MIXED_STATE * sizeof(int32_t)));
-    m.state = c->mixed_state + (size_t)c->mixed_state_next * SERL_MIXED_STATE;
+    state_slot = c->mixed_state_next;
+    m.state = c->mixed_state + (size_t)state_slot * SERL_MIXED_STATE;
     c->mixed_state_next = (c->mixed_state_next + 1) % SERL_MIXED_STATES;
+    // (two launches must never count into one census: the workgroups would disagree about the assignment)
+    if (c->mixed_ev[state_slot]) HIP_TRY(hipStreamWaitEvent(stream, c->mixed_ev[state_slot], 0));
+    else HIP_TRY(hipEventCreateWithFlags(&c->mixed_ev[state_slot], hipEventDisableTiming));
     HIP_TRY(hipMemsetAsync(m.state, 0, SERL_MIXED_STATE * sizeof(int32_t), stream));
   }
   const bool queue = together > 4 * c->num_cus;      // beyond four per CU: every part drains a work queue of its own on its share of the CUs
@@ -642,6 +648,7 @@ int serl_rollout_multi(serl_ctx *c, int32_t n, const serl_rollout_desc *descs, v
   HIP_TRY(hipEventRecord(c->ev0, stream));
   serl_launch_rollout_team4_mixed(m, wg, stream);
   HIP_TRY(hipGetLastError());
+  if (state_slot >= 0) HIP_TRY(hipEventRecord(c->mixed_ev[state_slot], stream));
   HIP_TRY(hipEventRecord(c->ev1, stream));
   c->timed = true;
   return SERL_OK;
