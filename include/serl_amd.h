@@ -232,6 +232,10 @@ int serl_dyn_open_loop(serl_ctx *ctx, int slot, int32_t n_episodes, int32_t T, c
  * workgroup 0: out[0..3] = {actor forward, dynamics step, env bookkeeping, env steps}; out[4..31] = phase
  * counters of the model evaluation (non-zero only in builds compiled with -DCITW_PROFILE). */
 int serl_debug_profile(serl_ctx *ctx, unsigned long long out[32]);
+/* Development aid: how the most recent serl_rollout_multi launch placed its workgroups.  out[0]: 0 = by blockIdx range (SERL_MIXED_PLACE=0, or one
+ * code variant only), 1 = by the census of the CU pairs, 2 = by tickets (SERL_MIXED_PLACE=1, or the census timed out: the GPU was shared);
+ * out[1] = workgroups that registered in the census; out[2] = CU pairs that held two of them, out[3] = one.  Blocks until the device is idle. */
+int serl_debug_mixed_placement(serl_ctx *ctx, int32_t out[4]);
 
 /* Duration (ms) of the most recent serl_rollout kernel on its stream, measured with HIP events
  * recorded around the launch; blocks until that kernel has finished. */

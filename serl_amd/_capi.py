@@ -9,7 +9,7 @@ VP = ctypes.c_void_p
 LIB_PATH = os.environ.get('SERL_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libserl_amd.so')
 
 EXPORTS = ['serl_abi_version', 'serl_last_error', 'serl_param_count', 'serl_ctx_create', 'serl_ctx_destroy',
-           'serl_ctx_load_build', 'serl_rollout', 'serl_rollout_multi', 'serl_dyn_open_loop', 'serl_debug_profile', 'serl_last_rollout_ms', 'serl_ga_clone', 'serl_ga_crossover',
+           'serl_ctx_load_build', 'serl_rollout', 'serl_rollout_multi', 'serl_dyn_open_loop', 'serl_debug_profile', 'serl_debug_mixed_placement', 'serl_last_rollout_ms', 'serl_ga_clone', 'serl_ga_crossover',
            'serl_ga_mutate', 'serl_ga_scaled_perturb', 'serl_abi_layout', 'serl_ga_sensitivity', 'serl_ga_novelty',
            'serl_replay_scatter', 'serl_env_state_dim', 'serl_env_action_dim',
            'serl_smoothness', 'serl_smoothness_work_size', 'serl_ga_distill', 'serl_host_sample_slots']
@@ -87,6 +87,7 @@ def lib():
     L.serl_rollout_multi.argtypes = [VP, ctypes.c_int32, ctypes.POINTER(RolloutDesc), VP]
     L.serl_dyn_open_loop.argtypes = [VP, ctypes.c_int, ctypes.c_int32, ctypes.c_int32, VP, VP, ctypes.c_int32, ctypes.c_int32, VP]
     L.serl_debug_profile.argtypes = [VP, ctypes.POINTER(ctypes.c_ulonglong)]
+    L.serl_debug_mixed_placement.argtypes = [VP, ctypes.POINTER(ctypes.c_int32)]
     L.serl_last_rollout_ms.argtypes = [VP, ctypes.POINTER(ctypes.c_float)]
     L.serl_ga_clone.argtypes = [VP, VP, ctypes.c_int64, ctypes.c_int32, VP, VP, ctypes.c_int32, VP]
     L.serl_ga_crossover.argtypes = [VP, VP, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, VP, ctypes.c_int32, VP]

@@ -608,9 +608,11 @@ int serl_rollout_multi(serl_ctx *c, int32_t n, const serl_rollout_desc *descs, v
   m.n = n;
   m.place = c->env_mixed_place;
   int state_slot = -1;
+  c->mixed_last = -1;
   if (m.place != 0) {
     if (!c->mixed_state) HIP_TRY(hipMalloc((void **)&c->mixed_state, SERL_MIXED_STATES * SERL_MIXED_STATE * sizeof(int32_t)));
     state_slot = c->mixed_state_next;
+    c->mixed_last = state_slot;
     m.state = c->mixed_state + (size_t)state_slot * SERL_MIXED_STATE;
     c->mixed_state_next = (c->mixed_state_next + 1) % SERL_MIXED_STATES;
     // (two launches must never count into one census: the workgroups would disagree about the assignment)
@@ -717,6 +719,20 @@ int serl_debug_profile(serl_ctx *c, unsigned long long out[32])
   if (!c || !out || !c->prof) return fail(SERL_E_INVALID, "serl_debug_profile: profiling not enabled (SERL_PROFILE=1)");
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(out, c->prof, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return SERL_OK;
+}
+
+int serl_debug_mixed_placement(serl_ctx *c, int32_t out[4])
+{
+  if (!c || !out) return fail(SERL_E_INVALID, "serl_debug_mixed_placement: NULL argument");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (!c->mixed_state || c->mixed_last < 0) return SERL_OK;          // no launch, or SERL_MIXED_PLACE=0
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());
+  int32_t h[SERL_MIXED_STATE];
+  HIP_TRY(hipMemcpy(h, c->mixed_state + (size_t)c->mixed_last * SERL_MIXED_STATE, sizeof(h), hipMemcpyDeviceToHost));
+  out[0] = c->env_mixed_place == 1 ? 2 : h[SERL_MIXED_UNITS + 1]; out[1] = h[SERL_MIXED_UNITS];
+  for (int u = 0; u < SERL_MIXED_UNITS; ++u) { out[2] += h[u] == 2; out[3] += h[u] == 1; }
   return SERL_OK;
 }
 

@@ -38,7 +38,7 @@ struct serl_ctx {
   unsigned env_jitter_sites = ~0u;      // SERL_JITTER_SITES: classes of sites that pause (citation_wave.h; all by default)
   int env_mixed_place = SERL_MIXED_PLACE_DEFAULT;      // SERL_MIXED_PLACE: how serl_rollout_multi places the parts' workgroups (serl_mixed.h)
   int32_t *mixed_state = nullptr;       // device [SERL_MIXED_STATES][SERL_MIXED_STATE]
-  int mixed_state_next = 0;
+  int mixed_state_next = 0, mixed_last = -1;            // (mixed_last: the state of the most recent launch, for serl_debug_mixed_placement)
   hipEvent_t mixed_ev[SERL_MIXED_STATES] = {};        // the launch that used a state last: a later launch on another stream waits for it before it zeroes the state
   unsigned env_jitter = 0;              // SERL_JITTER_SEED: seed of the hand-over stress builds' pauses (libserl_amd_jitter.so; the product ignores it)
   BuildSlot slots[SERL_MAX_SLOTS];

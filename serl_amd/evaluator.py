@@ -208,6 +208,13 @@ class RolloutEngine:
         self.multi_launches += 1
         return True
 
+    def mixed_placement(self):
+        """How the most recent rollout_multi launch placed its workgroups (development aid, include/serl_amd.h serl_debug_mixed_placement):
+        dict(decision = 0 blockIdx ranges | 1 census of the CU pairs | 2 tickets, registered, pairs, singles).  Waits for the device."""
+        out = (ctypes.c_int32 * 4)()
+        _capi.check(self.lib.serl_debug_mixed_placement(self.ctx, out), 'serl_debug_mixed_placement')
+        return dict(decision=int(out[0]), registered=int(out[1]), pairs=int(out[2]), singles=int(out[3]))
+
     def dynamics_open_loop(self, cmds, build='h2000_v90', lanes_per_wave=0, kernel=None):
         """Dynamics only: cmds f64 [E, T, 10] -> states f64 [E, T, 12] (what the reference's raw
         initialize()/step() return for the same command sequence)."""
