@@ -144,7 +144,7 @@ def main():
     ap.add_argument('--lanes', type=int, default=0, help='episodes per wavefront (0 = auto)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-partition-check', action='store_true')
-    ap.add_argument('--fused', action='store_true', help='mixed workload: ONE launch of one code object whatever the size (default: beyond 4 x CUs episodes)')
+    ap.add_argument('--fused', action='store_true', help='mixed workload: ONE launch of one code object (the default whenever the library takes the combination; kept for A/B scripts)')
     ap.add_argument('--no-fused', action='store_true', help='mixed workload: a launch per dynamics build side by side instead of ONE launch of one code object (A/B)')
     ap.add_argument('--strong-legs', choices=['auto', 'on', 'off'], default='auto', help='append the strong-scaling legs (pop=512, mixed pop=2048) to the line: auto = when N > 1 and no --total-pop / --pop')
     ap.add_argument('--dry-partition', action='store_true', help='print the member / episode blocks of every rank for --gpus N [--total-pop M | --pop P] and exit: no GPU, no launcher')
@@ -268,7 +268,7 @@ def measure(a, ctx):
                 sm = guess[0]
                 pending.append((guess[1], out['actions']))
             ls_host = None
-        else:      # one launch per dynamics build, side by side on streams of their own (evaluate_pop)
+        else:      # several dynamics builds: ONE launch of one code object, or (--no-fused) one per build side by side on streams of their own (evaluate_pop)
             r = serl_amd.evaluate_pop(wd, mode=modes_, num_evals=ne, refs=refd, t_max=80, spec=spec, engine=eng, fused=False if getattr(a, 'no_fused', False) else (True if getattr(a, 'fused', False) else 'auto'))
             tod = lambda x: torch.as_tensor(np.ascontiguousarray(x.T).reshape(-1), device=dev)
             fit, sm, lt, cs = tod(r.returns), tod(r.smoothness), tod(r.length_t), tod(r.cost_steps).double()

@@ -272,8 +272,8 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
     concurrent : False = the per-build launches run one after the other (A/B switch)
     fused      : several builds as ONE launch of one code object (C ABI v7 serl_rollout_multi), its workgroups placed so that CUs which share an
                  instruction cache run the same code variant.  'auto' (default) and True: whenever the library accepts the combination (more than
-                 2 x CUs episodes, attitude task, hidden 32, nominal / ice code): 768 episodes 33.8 against 30.4 M env-steps/s for a launch per build
-                 side by side, 6 144 episodes 40.0 against 36.4 M (profiles/r05_experiments.md sections 9, 11); False: never
+                 2 x CUs episodes, attitude task, hidden 32, nominal / ice code): 768 episodes 33.8 against 30.1 M env-steps/s for a launch per build
+                 side by side, 6 144 episodes 39.9 against 36.4 M (profiles/r05_experiments.md sections 9, 11); False: never
     sensor_rng : modes 'noise' / 'gust' add the reference's sensor model to what step() returns; its randn draws
              come from this legacy generator (None = np.random, like the wrappers), one block of T + 1 steps per
              noisy episode in episode order, up front (builds.sensor_noise_table)
