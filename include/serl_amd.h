@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SERL_ABI_VERSION 7
+#define SERL_ABI_VERSION 8
 
 enum serl_error {
   SERL_OK = 0,
@@ -236,6 +236,25 @@ int serl_debug_profile(serl_ctx *ctx, unsigned long long out[32]);
  * code variant only), 1 = by the census of the CU pairs, 2 = by tickets (SERL_MIXED_PLACE=1, or the census timed out: the GPU was shared);
  * out[1] = workgroups that registered in the census; out[2] = CU pairs that held two of them, out[3] = one.  Blocks until the device is idle. */
 int serl_debug_mixed_placement(serl_ctx *ctx, int32_t out[4]);
+
+/* ABI v8.  WHAT the most recent serl_rollout / serl_rollout_multi call of this context launched -- the kernel family is chosen by the library
+ * (episode count, actor shape, env configuration, kernel_hint), so a caller that compares families, or a test that names one, asks here which
+ * one actually ran (the seam being replaced is the one loop `for net in pop: for i in range(num_evals): evaluate(net)`,
+ * /root/reference/base/core/agent.py:234-241, which has no such choice).  Host-side record of the call: does not wait for the device.
+ *   out[0] enum serl_kernel_family        out[1] workgroups of the (last) launch     out[2] episodes per team / per wavefront (LANE: lanes)
+ *   out[3] 1 = the launch drains a work queue (a lane group takes the next episode when its own ends)
+ *   out[4] actor wavefronts beside the team wavefronts (0: the family has none)       out[5] 1 = the actor streams its weights from L2 (0: LDS-resident)
+ *   out[6] launches the call made (rounds of workgroups)                              out[7] enum serl_dyn_code of the launch, -1 = several (mixed sweep)
+ * SERL_E_INVALID before the first rollout of the context. */
+enum serl_kernel_family { SERL_FAMILY_NONE = 0, SERL_FAMILY_TEAM = 1 /* eight wavefronts = one episode, actor weights in LDS */,
+                          SERL_FAMILY_TEAMS = 2 /* ... the actor wavefront streams its weights (hidden 72 / 96) */,
+                          SERL_FAMILY_TEAMS2 = 3 /* ... two actor wavefronts share the forward pass (SERL_SPLIT_ACTOR=1) */,
+                          SERL_FAMILY_TEAMX = 4 /* ... env configurations other than the attitude task */,
+                          SERL_FAMILY_TEAM2 = 5 /* two episodes per team */, SERL_FAMILY_TEAM2S = 6 /* ... six team + two streaming actor wavefronts */,
+                          SERL_FAMILY_TEAM4 = 7 /* four episodes per team */, SERL_FAMILY_TEAM4_MIXED = 8 /* ... several code variants in one launch */,
+                          SERL_FAMILY_HALF = 9 /* one wavefront = two episodes */, SERL_FAMILY_WAVE = 10 /* one wavefront = one episode */,
+                          SERL_FAMILY_WAVEX = 11 /* ... other env configurations */, SERL_FAMILY_LANE = 12 /* one lane = one episode */ };
+int serl_last_rollout_info(serl_ctx *ctx, int32_t out[8]);
 
 /* Duration (ms) of the most recent serl_rollout kernel on its stream, measured with HIP events
  * recorded around the launch; blocks until that kernel has finished. */

@@ -9,7 +9,7 @@ VP = ctypes.c_void_p
 LIB_PATH = os.environ.get('SERL_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc', 'libserl_amd.so')
 
 EXPORTS = ['serl_abi_version', 'serl_last_error', 'serl_param_count', 'serl_ctx_create', 'serl_ctx_destroy',
-           'serl_ctx_load_build', 'serl_rollout', 'serl_rollout_multi', 'serl_dyn_open_loop', 'serl_debug_profile', 'serl_debug_mixed_placement', 'serl_last_rollout_ms', 'serl_ga_clone', 'serl_ga_crossover',
+           'serl_ctx_load_build', 'serl_rollout', 'serl_rollout_multi', 'serl_dyn_open_loop', 'serl_debug_profile', 'serl_debug_mixed_placement', 'serl_last_rollout_ms', 'serl_last_rollout_info', 'serl_ga_clone', 'serl_ga_crossover',
            'serl_ga_mutate', 'serl_ga_scaled_perturb', 'serl_abi_layout', 'serl_ga_sensitivity', 'serl_ga_novelty',
            'serl_replay_scatter', 'serl_env_state_dim', 'serl_env_action_dim',
            'serl_smoothness', 'serl_smoothness_work_size', 'serl_ga_distill', 'serl_host_sample_slots']
@@ -52,7 +52,9 @@ class ReplayJob(ctypes.Structure):
 
 # serl_rollout_desc.kernel_hint (enum serl_kernel_hint)
 KERNEL_HINTS = {None: 0, 'auto': 0, 'team': 1, 'wave': 2, 'half': 3, 'team2': 4, 'team4': 5}
-ABI_VERSION = 7
+ABI_VERSION = 8
+# serl_last_rollout_info out[0] (enum serl_kernel_family)
+FAMILIES = {0: None, 1: 'team', 2: 'teams', 3: 'teams2', 4: 'teamx', 5: 'team2', 6: 'team2s', 7: 'team4', 8: 'team4_mixed', 9: 'half', 10: 'wave', 11: 'wavex', 12: 'lane'}
 
 
 def expected_layout():
@@ -89,6 +91,7 @@ def lib():
     L.serl_debug_profile.argtypes = [VP, ctypes.POINTER(ctypes.c_ulonglong)]
     L.serl_debug_mixed_placement.argtypes = [VP, ctypes.POINTER(ctypes.c_int32)]
     L.serl_last_rollout_ms.argtypes = [VP, ctypes.POINTER(ctypes.c_float)]
+    L.serl_last_rollout_info.argtypes = [VP, ctypes.POINTER(ctypes.c_int32)]
     L.serl_ga_clone.argtypes = [VP, VP, ctypes.c_int64, ctypes.c_int32, VP, VP, ctypes.c_int32, VP]
     L.serl_ga_crossover.argtypes = [VP, VP, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, VP, ctypes.c_int32, VP]
     L.serl_ga_mutate.argtypes = [VP, VP, ctypes.c_int64, ctypes.c_int32, VP, VP, VP, VP, ctypes.c_int32, VP]

@@ -134,10 +134,13 @@ static bool serl_use_team(const serl_ctx *c, int hint, int episodes)
   return episodes <= c->num_cus;
 }
 
+// (rollout_device.h: serl_lds_actor_ok) the actor shape whose weights live in LDS for the episode
+static bool serl_lds_actor_shape(const serl_rollout_desc &d) { return d.hidden == 32 && d.num_layers <= 3 && d.state_dim == 7 && d.action_dim == 3; }
+
 static void serl_launch_rollout_team(int code, const RolloutArgs &a, int grid, hipStream_t stream, bool split_actor = false)
 {
   // (rollout_device.h: serl_lds_actor_ok) shapes whose weights the actor wavefront streams have a kernel of their own
-  const bool lds_actor = a.d.hidden == 32 && a.d.num_layers <= 3 && a.d.state_dim == 7 && a.d.action_dim == 3;
+  const bool lds_actor = serl_lds_actor_shape(a.d);
   if (!lds_actor && split_actor && a.d.hidden > 64 && a.d.hidden <= 128) {
     // (development override SERL_SPLIT_ACTOR=1) two actor wavefronts share ONE forward pass beside a six-wavefront team: round 4
     // built it for the shapes whose lone actor wavefront needed a whole step (H = 72: 43 k cycles) -- and then found that a
@@ -252,6 +255,13 @@ static int serl_waves_per_block(const serl_ctx *c, int waves)
 
 // descriptor hint first, then the context's development override (SERL_KERNEL, read once by serl_ctx_create)
 static int serl_resolve_hint(const serl_ctx *c, int desc_hint) { return desc_hint != SERL_KERNEL_AUTO ? desc_hint : c->env_kernel; }
+
+// serl_last_rollout_info's record of a call (include/serl_amd.h)
+static void serl_note_launch(serl_ctx *c, int family, int grid, int per_team, bool queue, int actor_waves, bool streamed, int launches, int code)
+{
+  const int32_t v[8] = {family, grid, per_team, queue ? 1 : 0, actor_waves, streamed ? 1 : 0, launches, code};
+  for (int i = 0; i < 8; ++i) c->last_info[i] = v[i];
+}
 
 extern "C" {
 
@@ -445,18 +455,22 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     if (team) {
       a.lanes = 1;
       a.block = 512;
+      int launches = 0, last = 0;
       for (int e0 = 0; e0 < d->n_episodes; e0 += c->num_cus) {
         const int n = d->n_episodes - e0 < c->num_cus ? d->n_episodes - e0 : c->num_cus;
         a.e0 = e0; a.e_end = e0 + n;
         serl_launch_rollout_teamx(s.code, a, n, stream);
         HIP_TRY(hipGetLastError());
+        ++launches; last = n;
       }
+      serl_note_launch(c, SERL_FAMILY_TEAMX, last, 1, false, 1, true, launches, s.code);
     } else {
       const int wpb = serl_wave_kernel_waves_per_block(c, together + (timed ? 0 : 16));
       a.lanes = 1;
       a.block = 64 * wpb;
       serl_launch_rollout_wavex(s.code, a, (d->n_episodes + wpb - 1) / wpb, stream);
       HIP_TRY(hipGetLastError());
+      serl_note_launch(c, SERL_FAMILY_WAVEX, (d->n_episodes + wpb - 1) / wpb, 1, false, 0, true, 1, s.code);
     }
     if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = timed;
@@ -468,6 +482,10 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
     serl_launch_rollout_team(s.code, a, d->n_episodes, stream, c->env_split_actor != 0);
     HIP_TRY(hipGetLastError());
+    {
+      const bool lds_actor = serl_lds_actor_shape(*d), split = !lds_actor && c->env_split_actor != 0 && d->hidden > 64 && d->hidden <= 128;
+      serl_note_launch(c, lds_actor ? SERL_FAMILY_TEAM : split ? SERL_FAMILY_TEAMS2 : SERL_FAMILY_TEAMS, d->n_episodes, 1, false, split ? 2 : 1, !lds_actor, 1, s.code);
+    }
     if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = timed;
     return SERL_OK;
@@ -489,6 +507,8 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     }
     serl_launch_rollout_teamg(s.code, teamg, a, grid, stream);
     HIP_TRY(hipGetLastError());
+    serl_note_launch(c, teamg == 4 ? SERL_FAMILY_TEAM4 : d->hidden != 32 ? SERL_FAMILY_TEAM2S : SERL_FAMILY_TEAM2, grid, teamg, a.queue != nullptr,
+                     (teamg == 2 && d->hidden != 32) ? 2 : 1, true /* the lane-group kernels' actor wavefronts stream the weights */, 1, s.code);
     if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = timed;
     return SERL_OK;
@@ -524,6 +544,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     }
     serl_launch_rollout_teamg(s.code, 4, a, grid, stream);
     HIP_TRY(hipGetLastError());
+    serl_note_launch(c, SERL_FAMILY_TEAM4, grid, 4, a.queue != nullptr, 1, true, 1, s.code);
     if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = timed;
     return SERL_OK;
@@ -538,6 +559,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
     serl_launch_rollout_half(s.code, a, grid, stream);
     HIP_TRY(hipGetLastError());
+    serl_note_launch(c, SERL_FAMILY_HALF, grid, 2, false, 0, true, 1, s.code);
     if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = timed;
     return SERL_OK;
@@ -552,6 +574,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
     serl_launch_rollout_wave(s.code, a, grid, stream);
     HIP_TRY(hipGetLastError());
+    serl_note_launch(c, SERL_FAMILY_WAVE, grid, 1, false, 0, true, 1, s.code);
     if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = timed;
     return SERL_OK;
@@ -575,6 +598,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   if (s.code == SERL_DYN_NOMINAL) serl_launch_rollout_nominal(a, grid, stream);
   else serl_launch_rollout_ice(a, grid, stream);
   HIP_TRY(hipGetLastError());
+  serl_note_launch(c, SERL_FAMILY_LANE, grid, lanes, false, 0, true, 1, s.code);
   if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
   c->timed = timed;
   return SERL_OK;
@@ -650,6 +674,11 @@ int serl_rollout_multi(serl_ctx *c, int32_t n, const serl_rollout_desc *descs, v
   HIP_TRY(hipEventRecord(c->ev0, stream));
   serl_launch_rollout_team4_mixed(m, wg, stream);
   HIP_TRY(hipGetLastError());
+  {
+    bool one_code = true;
+    for (int k = 1; k < n; ++k) one_code = one_code && m.code[k] == m.code[0];
+    serl_note_launch(c, SERL_FAMILY_TEAM4_MIXED, wg, 4, queue, 1, true, 1, one_code ? m.code[0] : -1);
+  }
   if (state_slot >= 0) HIP_TRY(hipEventRecord(c->mixed_ev[state_slot], stream));
   HIP_TRY(hipEventRecord(c->ev1, stream));
   c->timed = true;
@@ -741,6 +770,14 @@ int serl_last_rollout_ms(serl_ctx *c, float *ms)
   if (!c || !ms || !c->timed) return fail(SERL_E_INVALID, "serl_last_rollout_ms: no rollout recorded");
   HIP_TRY(hipEventSynchronize(c->ev1));
   HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return SERL_OK;
+}
+
+int serl_last_rollout_info(serl_ctx *c, int32_t out[8])
+{
+  if (!c || !out) return fail(SERL_E_INVALID, "serl_last_rollout_info: NULL argument");
+  if (c->last_info[0] == SERL_FAMILY_NONE) return fail(SERL_E_INVALID, "serl_last_rollout_info: no rollout recorded");
+  for (int i = 0; i < 8; ++i) out[i] = c->last_info[i];
   return SERL_OK;
 }
 

@@ -47,4 +47,5 @@ struct serl_ctx {
   unsigned long long *prof = nullptr;   // device [32], allocated when SERL_PROFILE=1
   int32_t *queue = nullptr;             // device [SERL_QUEUE_COUNTERS]: work-queue counters of the multi-episode team kernels, one per LAUNCH (a ring)
   int queue_next = 0;
+  int32_t last_info[8] = {};            // serl_last_rollout_info: what the most recent rollout call launched (family, workgroups, episodes per team, queue, actor wavefronts, streamed, launches, code)
 };

@@ -208,6 +208,15 @@ class RolloutEngine:
         self.multi_launches += 1
         return True
 
+    def last_rollout_info(self):
+        """WHAT the most recent rollout / rollout_multi call launched (C ABI v8 serl_last_rollout_info): dict(family = 'team' | 'teams' | 'teams2' |
+        'teamx' | 'team2' | 'team2s' | 'team4' | 'team4_mixed' | 'half' | 'wave' | 'wavex' | 'lane', workgroups, episodes_per_team, work_queue,
+        actor_wavefronts, actor_streamed, launches, code).  Does not wait for the device."""
+        out = (ctypes.c_int32 * 8)()
+        _capi.check(self.lib.serl_last_rollout_info(self.ctx, out), 'serl_last_rollout_info')
+        return dict(family=_capi.FAMILIES[int(out[0])], workgroups=int(out[1]), episodes_per_team=int(out[2]), work_queue=bool(out[3]),
+                    actor_wavefronts=int(out[4]), actor_streamed=bool(out[5]), launches=int(out[6]), code=int(out[7]))
+
     def mixed_placement(self):
         """How the most recent rollout_multi launch placed its workgroups (development aid, include/serl_amd.h serl_debug_mixed_placement):
         dict(decision = 0 blockIdx ranges | 1 census of the CU pairs | 2 tickets, registered, pairs, singles).  Waits for the device."""

@@ -29,6 +29,24 @@ def test_c_abi_exports_every_declared_symbol():
     assert L.serl_param_count(7, 32, 3, 3) == 3715 and L.serl_param_count(7, 72, 3, 3) == 16995
 
 
+def test_documented_raw_binding_asserts_the_current_abi_version():
+    """INTEGRATION.md section 2 is a binding a maintainer copies: the version literal it asserts must be the header's (round 5 shipped a v7 library
+    with a document that asserted 6), and the family names of the Python binding must cover enum serl_kernel_family."""
+    from serl_amd import _capi
+    hdr = open(os.path.join(ROOT, 'include', 'serl_amd.h')).read()
+    ver = int(re.search(r'#define SERL_ABI_VERSION (\d+)', hdr).group(1))
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    lits = [int(v) for v in re.findall(r'serl_abi_version\(\) == (\d+)', doc)]
+    assert lits and all(v == ver for v in lits), (lits, ver)
+    assert _capi.ABI_VERSION == ver
+    fam = re.search(r'enum serl_kernel_family \{(.*?)\};', hdr, re.S).group(1)
+    fam = re.sub(r'/\*.*?\*/', '', fam, flags=re.S)
+    vals = {int(v): n for n, v in re.findall(r'SERL_FAMILY_([A-Z0-9_]+) = (\d+)', fam)}
+    assert sorted(vals) == sorted(_capi.FAMILIES), (vals, _capi.FAMILIES)
+    for v, n in vals.items():
+        assert (_capi.FAMILIES[v] or 'none').upper() == n, (v, n, _capi.FAMILIES[v])
+
+
 def test_no_cpu_fallback_in_the_product():
     import serl_amd
     if torch.cuda.is_available():

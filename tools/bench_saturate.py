@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""SURVEY 8d's SATURATING configuration: many more episodes than the GPU has lane groups, where throughput -- not the latency of one env step --
+is the regime and the fp64 fraction means something.
+
+    python tools/bench_saturate.py [--episodes 16384,65536] [--t-max 20] [--members 2048] [--modes lane64,auto] [--reps 2]
+
+For every episode count and mode one JSON line: env-steps/s of the rollout kernel (HIP events around the launch), the kernel family the library
+launched (serl_last_rollout_info), the fraction of the MEASURED fp64 peak (profiles/valu_latency_current.json) by SURVEY 8d's F_alg = 24 059 f64
+operations per env step, and -- for the first 64 episodes -- whether the results equal the one-episode-per-team kernel's bit for bit.
+Modes: laneN = the lane-per-episode DAG kernels with N episodes per wavefront (lanes_per_wave = N, rollout_variant.inc); auto = what serl_rollout
+chooses (four episodes per team + work queue beyond 4 x CUs episodes); half = two episodes per wavefront.
+Workload: the shipped SERL50 actors tiled with seeded noise to `members`, member = episode mod members, the base reference of
+/root/reference/base/evaluate.py:173-180 shared by all episodes, nominal build, t_max seconds (2 001 env steps at 20 s)."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import bench, serl_amd
+from serl_amd import refsignals
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--episodes', default='16384,65536')
+ap.add_argument('--t-max', type=float, default=20.0)
+ap.add_argument('--members', type=int, default=2048)
+ap.add_argument('--modes', default='lane64,auto')
+ap.add_argument('--reps', type=int, default=2)
+a = ap.parse_args()
+eng = serl_amd.RolloutEngine(0)
+spec = serl_amd.NetSpec(7, 3, 32, 3, 'tanh')
+w = bench.make_population(a.members, 0, tag='serl50').to(eng.device)
+ref = refsignals.tabulate(*refsignals.base_reference(a.t_max), a.t_max)
+T = ref.shape[0]
+try:
+    peak = float(json.load(open(os.path.join(ROOT, 'profiles', 'valu_latency_current.json')))['fp64_fma_peak_tflops_measured'])
+except Exception:
+    peak = None
+base = None
+for E in [int(x) for x in a.episodes.split(',')]:
+    moe = (np.arange(E) % a.members).astype(np.int32)
+    for mode in a.modes.split(','):
+        kw = dict(lanes_per_wave=int(mode[4:])) if mode.startswith('lane') else dict(kernel=None if mode == 'auto' else mode)
+        ms = []
+        try:
+            for _ in range(a.reps):
+                out = eng.rollout(w, spec, moe, ref, t_max=a.t_max, **kw)
+                ms.append(eng.last_kernel_ms)
+        except Exception as ex:
+            print(json.dumps(dict(episodes=E, mode=mode, error=repr(ex)[:300])), flush=True)
+            continue
+        steps = int(out['length_steps'].abs().sum())
+        info = eng.last_rollout_info()
+        k_ms = min(ms)
+        rate = steps / (k_ms * 1e-3)
+        chk = eng.rollout(w, spec, moe[:64], ref, t_max=a.t_max, kernel='team')
+        same = bool(torch.equal(chk['fitness'], out['fitness'][:64]) and torch.equal(chk['length_steps'], out['length_steps'][:64]))
+        print(json.dumps(dict(what='saturating configuration (SURVEY 8d)', episodes=E, steps_per_episode=T, members=a.members, mode=mode, family=info['family'],
+                              workgroups=info['workgroups'], episodes_per_team_or_wave=info['episodes_per_team'], work_queue=info['work_queue'],
+                              kernel_ms=[round(v, 2) for v in ms], env_steps=steps, env_steps_per_s=rate,
+                              us_per_env_step_and_wavefront_or_team=k_ms * 1e3 / T,
+                              fp64_tflops_by_F_alg=rate * bench.F_ALG / 1e12, fp64_frac_of_measured_peak=(rate * bench.F_ALG / 1e12 / peak) if peak else None,
+                              fp64_peak_measured_tflops=peak, first_64_episodes_equal_one_per_team=same)), flush=True)

@@ -9,8 +9,13 @@
 #   bench:<args>     bench.py with the given arguments (commas for spaces), e.g. bench:--workload,serl10,--no-cpu-baseline
 #   pmc              the SQ issue counters + FETCH / WRITE sizes of one evaluation (separate passes, MI355X_MICROARCH.md)
 #   icache:<args>    instruction-cache counters (SQC_ICACHE_REQ / HITS / MISSES / MISSES_DUPLICATE, SQ_IFETCH) of one evaluation of bench.py <args>
+#   pcsamp:<lib>:<args>   PC sampling (rocprofv3 --pc-sampling-beta-enabled) of bench.py <args> --steps 1 --warmup 0 on library <lib> (default | the tag of
+#                    libserl_amd_<tag>.so; `g` = the product's code with line tables): tools/pcsamp.py collect -> <tag>/pcsamp_<lib>_<args>.json
+#   ldspmc:<lib,...> LDS counters (SQ_LDS_BANK_CONFLICT / ADDR_CONFLICT / IDX_ACTIVE / UNALIGNED_STALL, SQ_INSTS_LDS, SQ_ACTIVE_INST_LDS, SQ_WAIT_INST_LDS) of one
+#                    evaluation of the default bench on each library
+#   saturate[:args]  tools/bench_saturate.py (SURVEY 8d's saturating configuration)
 #   profile          tools/profile_round.sh <tag> (the round's whole profile series)
-#   py:<script.py>   any script of the repo
+#   py:<script.py>[,arg,...]   any script of the repo
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
@@ -49,10 +54,29 @@ for STEP in "$@"; do
        timeout 600 rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU -d $O/pmc_ic$N -o pi -- python $R/bench.py $A --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_ic$N.log 2>&1)
       python tools/pmc_summary.py $O/pmc_ic$N > $O/pmc_ic$N.json 2>> $O/err.txt; rm -rf $O/pmc_ic$N
       tr -d '\n' < $O/pmc_ic$N.json | cut -c1-500; echo ;;
+    pcsamp:*)
+      REST=${STEP#pcsamp:}; L=${REST%%:*}; A=$(echo ${REST#*:} | tr ',' ' '); N=$(echo ${REST} | tr -c 'a-zA-Z0-9' '_')
+      LIBARG=""; [ $L != default ] && LIBARG="--lib $R/serl_amd/csrc/libserl_amd_$L.so"
+      timeout 2400 python tools/pcsamp.py collect $O/pcsamp_$N.json $LIBARG -- python $R/bench.py $A --steps 1 --warmup 0 --no-cpu-baseline > $O/pcsamp_$N.log 2>&1
+      tail -n 8 $O/pcsamp_$N.log | cut -c1-400 ;;
+    ldspmc:*)
+      for L in $(echo ${STEP#ldspmc:} | tr ',' ' '); do
+        LIBENV=""; [ $L != default ] && LIBENV="SERL_LIB=$R/serl_amd/csrc/libserl_amd_$L.so"
+        (cd /tmp && export TMPDIR=/tmp
+         P1="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline"
+         env $LIBENV timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES -d $O/pmc_lds_$L -o pl -- $P1 > $O/pmc_lds_$L.log 2>&1
+         env $LIBENV timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INST_LEVEL_LDS -d $O/pmc_sq_$L -o ps -- $P1 > $O/pmc_sq_$L.log 2>&1)
+        for k in lds sq; do python tools/pmc_summary.py $O/pmc_${k}_$L > $O/pmc_${k}_$L.json 2>> $O/err.txt; rm -rf $O/pmc_${k}_$L; done
+        echo $L; tr -d '\n' < $O/pmc_lds_$L.json | cut -c1-600; echo
+      done ;;
+    saturate*)
+      A=$(echo ${STEP#saturate} | tr ':,' '  ')
+      timeout 1500 python tools/bench_saturate.py $A > $O/saturate.jsonl 2>> $O/err.txt; cut -c1-420 $O/saturate.jsonl ;;
     profile)
       bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1 ;;
     py:*)
-      timeout 900 python ${STEP#py:} > $O/$(basename ${STEP#py:} .py).txt 2>> $O/err.txt; tail -n 5 $O/$(basename ${STEP#py:} .py).txt ;;
+      A=$(echo ${STEP#py:} | tr ',' ' '); S1=${STEP#py:}; S1=${S1%%,*}
+      timeout 900 python $A > $O/$(basename $S1 .py).txt 2>> $O/err.txt; tail -n 5 $O/$(basename $S1 .py).txt | cut -c1-1200 ;;
   esac
 done
 [ -f $O/err.txt ] && tail -n 3 $O/err.txt
