@@ -245,7 +245,7 @@ int serl_debug_mixed_placement(serl_ctx *ctx, int32_t out[4]);
  *   out[3] 1 = the launch drains a work queue (a lane group takes the next episode when its own ends)
  *   out[4] actor wavefronts beside the team wavefronts (0: the family has none)       out[5] 1 = the actor streams its weights from L2 (0: LDS-resident)
  *   out[6] launches the call made (rounds of workgroups)                              out[7] enum serl_dyn_code of the launch, -1 = several (mixed sweep)
- * SERL_E_INVALID before the first rollout of the context. */
+ * serl_dyn_open_loop records its launch too (families TEAM / WAVE / LANE, no actor wavefront).  SERL_E_INVALID before the first launch of the context. */
 enum serl_kernel_family { SERL_FAMILY_NONE = 0, SERL_FAMILY_TEAM = 1 /* eight wavefronts = one episode, actor weights in LDS */,
                           SERL_FAMILY_TEAMS = 2 /* ... the actor wavefront streams its weights (hidden 72 / 96) */,
                           SERL_FAMILY_TEAMS2 = 3 /* ... two actor wavefronts share the forward pass (SERL_SPLIT_ACTOR=1) */,

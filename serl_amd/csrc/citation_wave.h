@@ -561,8 +561,12 @@ static __device__ __forceinline__ void citw_search_pass(const int wv, const Citw
     citw_sidx_changed();
   }
 #else
+  // (no hint: the full count every time.  An interval that moves must still be counted, or the table lanes of CitwPassCache keep stale
+  // x0 / quotients / corners -- citw_lookup2d_part_c, citw_lookup1d_part_c refill only when g_smiss has moved)
   const int idx = citw_search_count<MAXN>(x, n, u);
+  const int old = *slot;
   if (valid) *slot = idx;
+  if (valid && idx != old) citw_sidx_changed();
 #endif
 }
 

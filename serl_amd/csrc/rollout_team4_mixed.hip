@@ -88,7 +88,12 @@ static __device__ __forceinline__ void serl_mixed_place(const SerlMixedArgs &m, 
         g_mixed_census[lane + 64 * i] = c;
         most = c > most ? c : most;
       }
-      if (__ballot(most > 2) != 0ull) dec = 2;          // (the same census, the same verdict in every workgroup)
+      if (__ballot(most > 2) != 0ull) {                 // (the same census, the same verdict in every workgroup)
+        dec = 2;
+        // ... and on the record: serl_debug_mixed_placement reports tickets, not the census (a device whose HW_ID-to-pair mapping collides
+        // would otherwise lose the placement silently); a workgroup that has not read the decision yet finds 2 and takes a ticket at once
+        if (lane == 0) __hip_atomic_store(decision, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     if (dec == 1) {
       if (lane == 0) {

@@ -645,6 +645,29 @@ int serl_rollout_multi(serl_ctx *c, int32_t n, const serl_rollout_desc *descs, v
     HIP_TRY(hipMemsetAsync(m.state, 0, SERL_MIXED_STATE * sizeof(int32_t), stream));
   }
   const bool queue = together > 4 * c->num_cus;      // beyond four per CU: every part drains a work queue of its own on its share of the CUs
+  // workgroups of every part: one per four episodes, or (queue) the part's share of the CUs
+  int grids[SERL_MIXED_MAX], total_wg = 0;
+  for (int k = 0; k < n; ++k) {
+    const serl_rollout_desc *d = descs + k;
+    grids[k] = (d->n_episodes + 3) / 4;
+    if (queue) {
+      int share = (int)((long long)c->num_cus * d->n_episodes / together);
+      share = share < 1 ? 1 : share;
+      if (share * 4 < d->n_episodes) grids[k] = share;
+    }
+    total_wg += grids[k];
+  }
+  // The census placement needs every workgroup resident, one per CU (a team fills a CU's LDS).  The parts round up on their own -- 341 / 341 / 342
+  // episodes on 256 CUs are 86 + 86 + 86 = 258 workgroups, and a share bumped to 1 does the same in queue mode -- so the overflow is taken from the
+  // largest part, which drains the episodes it loses through its work queue.
+  while (total_wg > c->num_cus) {
+    int big = 0;
+    for (int k = 1; k < n; ++k) big = grids[k] > grids[big] ? k : big;
+    if (grids[big] <= 1) break;
+    const int cut = total_wg - c->num_cus < grids[big] - 1 ? total_wg - c->num_cus : grids[big] - 1;
+    grids[big] -= cut; total_wg -= cut;
+  }
+  if (total_wg > c->num_cus && m.place == 2) m.place = 1;      // (more parts than CUs: never all resident -- tickets at once instead of the census' time-out)
   int wg = 0;
   for (int k = 0; k < n; ++k) {
     const serl_rollout_desc *d = descs + k;
@@ -652,17 +675,12 @@ int serl_rollout_multi(serl_ctx *c, int32_t n, const serl_rollout_desc *descs, v
     serl_fill_args(c, d, a);
     a.lanes = 1;
     a.block = 512;
-    int grid = (d->n_episodes + 3) / 4;
+    const int grid = grids[k];
     a.queue = nullptr; a.q0 = d->n_episodes;
-    if (queue) {
-      int share = (int)((long long)c->num_cus * d->n_episodes / together);
-      share = share < 1 ? 1 : share;
-      if (share * 4 < d->n_episodes) {
-        grid = share;
-        a.queue = serl_next_queue_counter(c);
-        a.q0 = 4 * grid;
-        HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(int32_t), stream));
-      }
+    if (grid * 4 < d->n_episodes) {
+      a.queue = serl_next_queue_counter(c);
+      a.q0 = 4 * grid;
+      HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(int32_t), stream));
     }
     m.first_wg[k] = wg;
     m.code[k] = c->slots[d->build_slot].code;
@@ -677,7 +695,9 @@ int serl_rollout_multi(serl_ctx *c, int32_t n, const serl_rollout_desc *descs, v
   {
     bool one_code = true;
     for (int k = 1; k < n; ++k) one_code = one_code && m.code[k] == m.code[0];
-    serl_note_launch(c, SERL_FAMILY_TEAM4_MIXED, wg, 4, queue, 1, true, 1, one_code ? m.code[0] : -1);
+    bool any_queue = false;
+    for (int k = 0; k < n; ++k) any_queue = any_queue || m.a[k].queue != nullptr;
+    serl_note_launch(c, SERL_FAMILY_TEAM4_MIXED, wg, 4, any_queue, 1, true, 1, one_code ? m.code[0] : -1);
   }
   if (state_slot >= 0) HIP_TRY(hipEventRecord(c->mixed_ev[state_slot], stream));
   HIP_TRY(hipEventRecord(c->ev1, stream));
@@ -708,6 +728,7 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
     HIP_TRY(hipEventRecord(c->ev0, stream));
     serl_launch_dyn_team(s.code, a, cmds, states, T, n_episodes, stream);
     HIP_TRY(hipGetLastError());
+    serl_note_launch(c, SERL_FAMILY_TEAM, n_episodes, 1, false, 0, false, 1, s.code);      // (dynamics only: the team without an actor wavefront)
     HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = true;
     return SERL_OK;
@@ -719,6 +740,7 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
     HIP_TRY(hipEventRecord(c->ev0, stream));
     serl_launch_dyn_wave(s.code, a, cmds, states, T, (n_episodes + wpb - 1) / wpb, stream);
     HIP_TRY(hipGetLastError());
+    serl_note_launch(c, SERL_FAMILY_WAVE, (n_episodes + wpb - 1) / wpb, 1, false, 0, false, 1, s.code);
     HIP_TRY(hipEventRecord(c->ev1, stream));
     c->timed = true;
     return SERL_OK;
@@ -736,6 +758,7 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
   if (s.code == SERL_DYN_NOMINAL) serl_launch_dyn_nominal(a, cmds, states, T, grid, stream);
   else serl_launch_dyn_ice(a, cmds, states, T, grid, stream);
   HIP_TRY(hipGetLastError());
+  serl_note_launch(c, SERL_FAMILY_LANE, grid, lanes, false, 0, false, 1, s.code);
   HIP_TRY(hipEventRecord(c->ev1, stream));
   c->timed = true;
   return SERL_OK;

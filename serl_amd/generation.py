@@ -245,11 +245,54 @@ def evaluate_generation_sharded(pop: Sequence, rl_agent=None, *, args, mode='nom
     return GenerationResult(pop=res, rl_episode=g.rl_episode, kernel_ms=g.kernel_ms)
 
 
+class ValidationHandle:
+    """A validation batch in flight on a side stream (validate_actor(wait=False)).  `result()` waits for ITS launch only and returns
+    validate_actor's tuple; `done()` polls.  Everything the tuple needs was copied to pinned host memory behind the kernel on the same stream."""
+
+    def __init__(self, event, host, refs, tests, smooth_fitness, keep, t0_event):
+        self._event, self._host, self._refs, self._tests, self._sf, self._keep, self._t0 = event, host, refs, tests, smooth_fitness, keep, t0_event
+        self._res = None
+
+    def done(self):
+        return self._res is not None or self._event.query()
+
+    def result(self):
+        if self._res is None:
+            self._event.synchronize()
+            h, tests = self._host, self._tests
+            self.stream_ms = float(self._t0.elapsed_time(self._event))      # rollout + smoothness + copies, as the side stream saw them
+            lsr = h['length_steps'].numpy()
+            if (lsr < 0).any():
+                raise RuntimeError('reference table too short: %d validation episodes were still running' % int((lsr < 0).sum()))
+            ls = np.abs(lsr)
+            sm = h['smoothness'].numpy()
+            rew = h['rewards'].numpy()
+            scores = np.array([float(np.sum(rew[e, :ls[e]])) for e in range(tests)])
+            lengths = h['length_t'].numpy()
+            e = tests - 1
+            n = int(ls[e])
+            fitness = float(np.sum(rew[e, :n])) + (float(sm[e]) if self._sf else 0.0)
+            ref_row = self._refs[e] if self._refs.ndim == 3 else self._refs
+            last = Episode(fitness=fitness, smoothness=float(sm[e]), length=float(lengths[e]), state_history=list(h['states_last'].numpy()[:n]),
+                           ref_signals=np.asarray(ref_row[n - 1]), actions=h['actions_last'].numpy()[:n].copy(), reward_lst=list(rew[e, :n]))
+            self._res = (float(np.mean(scores)), float(np.std(scores)), float(np.mean(lengths)), float(np.std(lengths)), last,
+                         float(np.median(sm)), float(np.std(sm)))
+            self._keep = None
+        return self._res
+
+
 def validate_actor(agent, *, tests=5, mode='nominal', t_max=20, refs=None, smooth_fitness=False,
-                   engine: Optional[RolloutEngine] = None):
+                   engine: Optional[RolloutEngine] = None, wait: bool = True, stream: Optional[torch.cuda.Stream] = None):
     """`Agent.validate_agent` (agent.py:188-209): `tests` episodes of one actor, nothing stored, all in one launch.
     Returns the reference's tuple (test_score, test_sd, ep_len, ep_len_sd, last_episode, sm, sm_sd):
-    mean / std of sum(reward_lst), mean / std of the episode length, the last episode, median / std of smoothness."""
+    mean / std of sum(reward_lst), mean / std of the episode length, the last episode, median / std of smoothness.
+
+    wait=False (SURVEY 8f-4 for real): the batch -- five one-episode teams, 2 % of the GPU -- is launched on a SIDE stream of the engine and a
+    `ValidationHandle` comes back at once; its results feed statistics only (agent.py:258-259, 274-275), so the champion's validation runs beside the
+    SSNE epoch and the RL actor's beside the next generation's population launch.  The side stream first waits for what the caller's stream has
+    enqueued (the TD3 update that produced the weights); smoothness and the copies of the results follow the kernel on the same stream, nothing
+    synchronises with the host until `handle.result()`.  Host RNG: this function draws nothing -- references are the caller's (`refs`), drawn when the
+    reference draws them -- so the order of the reference's streams is the caller's call order, wait or not."""
     engine = engine or default_engine()
     actor = _actor_of(agent)
     actor.eval()
@@ -260,6 +303,28 @@ def validate_actor(agent, *, tests=5, mode='nominal', t_max=20, refs=None, smoot
     if refs.dim() == 3:
         assert refs.shape[0] == tests
     build, row = builds.resolve_mode(mode)
+    if not wait:
+        side = stream or engine.side_stream(2)
+        side.wait_stream(torch.cuda.current_stream(engine.device))
+        with torch.cuda.stream(side):
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record(side)
+            # beside other launches: told that the rest of the GPU is taken (the one pair of timing events of the context stays the main stream's)
+            out = engine.rollout(pack_population([actor]), spec, np.zeros(tests, dtype=np.int32), refs, build=build,
+                                 faults=None if row == builds.NOMINAL_ROW else [row] * tests, t_max=t_max, traces=True, sync=False,
+                                 concurrent_episodes=max(1, engine.num_cus - tests))
+            sm = metrics.calc_smoothness_enqueued(out['actions'], out['length_steps'])
+            if sm is None:
+                raise RuntimeError('validate_actor(wait=False): the smoothness kernel does not take traces of %d steps' % out['actions'].shape[1])
+            e = tests - 1
+            host = {}
+            for name, src in (('length_steps', out['length_steps']), ('length_t', out['length_t']), ('smoothness', sm), ('rewards', out['rewards']),
+                              ('states_last', out['states'][e]), ('actions_last', out['actions'][e])):
+                host[name] = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+                host[name].copy_(src, non_blocking=True)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(side)
+        return ValidationHandle(ev, host, refs.cpu().numpy(), tests, smooth_fitness, (out, sm), t0)
     out = engine.rollout(pack_population([actor]), spec, np.zeros(tests, dtype=np.int32), refs, build=build,
                          faults=None if row == builds.NOMINAL_ROW else [row] * tests, t_max=t_max, traces=True)
     ls = np.abs(out['length_steps'].cpu().numpy())

@@ -114,7 +114,18 @@ def calc_smoothness_after_miss(actions, length_steps, dt=0.01):
     return sm
 
 
-def _smoothness_dft(actions, lengths, dt):
+def calc_smoothness_enqueued(actions, length_steps, dt=0.01):
+    """calc_smoothness of episodes of ANY lengths without a host round trip: the direct-DFT kernel (csrc/serl_metrics.hip) on the current stream with
+    the lengths read ON THE DEVICE (|length_steps|, what the rollout kernel wrote) and its twiddle table sized for the whole trace.  What the
+    asynchronous validation batches use (generation.validate_actor(wait=False)): nothing between the rollout launch and the results' copy waits for
+    the host.  actions f64 [E, T, 3] on the GPU, T <= 8192; returns f64 [E] on the device, or None when the kernel does not take the shape."""
+    E, T, A = actions.shape
+    if not actions.is_cuda or A != 3 or T > 8192:
+        return None
+    return _smoothness_dft(actions, torch.as_tensor(length_steps).abs(), dt, max_len=max(T, 4))
+
+
+def _smoothness_dft(actions, lengths, dt, max_len=None):
     import ctypes
     from . import _capi, evaluator
     with torch.cuda.device(actions.device):
@@ -125,7 +136,7 @@ def _smoothness_dft(actions, lengths, dt):
     a = actions.contiguous()
     E, T, _ = a.shape
     n = lengths.to(torch.int32).to(a.device)
-    mx = max(int(lengths.max()), 4)                      # twiddle table / frequency chunks sized for the longest of them
+    mx = max_len if max_len is not None else max(int(lengths.max()), 4)      # twiddle table / frequency chunks sized for the longest of them
     work = torch.empty(int(L.serl_smoothness_work_size(E, mx)), dtype=torch.float64, device=a.device)
     out = torch.empty(E, dtype=torch.float64, device=a.device)
     stream = torch.cuda.current_stream(a.device).cuda_stream

@@ -57,7 +57,7 @@ class _Critic(torch.nn.Module):
         return self.q1(x), self.q2(x)
 
 
-def epoch(fitness):
+def epoch(fitness, sync=True):
     """the reference's DEFAULT SSNE epoch (proximal mutation, distillation crossover, distance-sorted groups;
     base/parameters.py:110-115) on the packed population with the generation's device rings"""
     import random
@@ -69,8 +69,37 @@ def epoch(fitness):
     wts = serl_amd.pack_population([a.actor for a in pop], device=engine.device)
     s = ssne.SSNE(eargs, engine, serl_amd.evaluator.spec_of(pop[0].actor), critic=critic)
     s.epoch(wts, fitness, buffers=[a.buffer for a in pop], critical=[a.critical_buffer for a in pop])
-    torch.cuda.synchronize()
+    if sync:
+        torch.cuda.synchronize()
+    else:
+        torch.cuda.current_stream().synchronize()      # (the caller's stream only: a validation batch may still be in flight on a side stream)
     return time.perf_counter() - t0
+
+
+def generation_overlapped(state, fit_for_epoch=None):
+    """The same generation with the validation batches in flight beside other work (validate_actor(wait=False)): the champion's batch beside the
+    SSNE epoch, the RL actor's beside the NEXT generation's population launch (its handle is `state['rl']`, waited for behind that launch)."""
+    t = {}
+    t0 = time.perf_counter()
+    refs = refsignals.ref_specs(*refsignals.training_references(E, 20, rng), 0.2106)
+    t['refs'] = time.perf_counter() - t0; t0 = time.perf_counter()
+    g = serl_amd.evaluate_generation(pop, rl, args=args, t_max=20, refs=refs, engine=engine, replay_buffer=shared, counters=counters)
+    torch.cuda.current_stream().synchronize()
+    t['evaluate_generation'] = time.perf_counter() - t0; t['kernel_generation'] = g.kernel_ms / 1e3; t0 = time.perf_counter()
+    if state.get('rl') is not None:
+        state['rl'].result()                       # the previous generation's RL validation: flew beside the launch above
+        t['stream_ms_validate_rl'] = state['rl'].stream_ms / 1e3
+    t['wait_validate_rl'] = time.perf_counter() - t0; t0 = time.perf_counter()
+    h1 = serl_amd.validate_actor(pop[g.pop.champion], tests=5, t_max=20, engine=engine, wait=False)
+    t['launch_validate_champion'] = time.perf_counter() - t0; t0 = time.perf_counter()
+    if fit_for_epoch is not None:
+        t['epoch'] = epoch(fit_for_epoch, sync=False)
+        t0 = time.perf_counter()
+    h1.result()
+    t['wait_validate_champion'] = time.perf_counter() - t0; t['stream_ms_validate_champion'] = h1.stream_ms / 1e3; t0 = time.perf_counter()
+    state['rl'] = serl_amd.validate_actor(rl, tests=5, t_max=20, engine=engine, wait=False)      # (behind the TD3 update in a training loop)
+    t['launch_validate_rl'] = time.perf_counter() - t0
+    return t
 
 
 critic = _Critic().to(engine.device)
@@ -90,6 +119,22 @@ if '--epoch' in sys.argv:
 mean = {k: float(np.mean([t[k] for t in ts])) * 1e3 for k in ts[0]}
 total = mean['refs'] + mean['evaluate_generation'] + mean['validate_champion'] + mean['validate_rl']
 steps = int(counters['num_frames'])
-print(json.dumps(dict(what='one generation: 151 + 5 + 5 episodes of 20 s (2 001 steps), drop-in API, ms', **{k: round(v, 2) for k, v in mean.items()},
-                      total_ms=round(total, 2), kernel_ms=round(mean['kernel_generation'] + 2 * mean['kernel_validate'], 2),
-                      stored_frames=steps, ssne_default_epoch_ms=[round(v, 1) for v in ep_ms])))
+# the same generations with the validation batches in flight (steady state: every generation waits for the previous one's RL validation)
+state = {}
+fit = np.random.default_rng(1).normal(-150, 50, 50) if '--epoch' in sys.argv else None
+generation_overlapped(state, fit)
+t_all = time.perf_counter()
+to = [generation_overlapped(state, fit) for _ in range(G)]
+wall_overlapped = (time.perf_counter() - t_all) / G * 1e3
+state['rl'].result()
+mo = {k: float(np.mean([t[k] for t in to if k in t])) * 1e3 for k in to[-1]}
+stage_overlapped = mo['refs'] + mo['evaluate_generation'] + mo['wait_validate_rl'] + mo['launch_validate_champion'] + mo['wait_validate_champion'] + mo['launch_validate_rl']
+print(json.dumps(dict(what='one generation: 151 + 5 + 5 episodes of 20 s (2 001 steps), drop-in API, ms', serial=dict({k: round(v, 2) for k, v in mean.items()},
+                      evaluation_stage_ms=round(total, 2), kernel_ms=round(mean['kernel_generation'] + 2 * mean['kernel_validate'], 2),
+                      ssne_default_epoch_ms=[round(v, 1) for v in ep_ms]),
+                      overlapped=dict({k: round(v, 2) for k, v in mo.items()}, evaluation_stage_ms=round(stage_overlapped - (0 if fit is None else 0.0), 2),
+                                      evaluation_stage_minus_kernel_generation_ms=round(stage_overlapped - mo['kernel_generation'], 2),
+                                      generation_wall_ms_with_epoch=round(wall_overlapped, 2) if fit is not None else None,
+                                      note='validate_actor(wait=False): the champion\'s batch flies beside the SSNE epoch, the RL actor\'s beside the next generation\'s population launch; '
+                                           'wait_* = what result() still waited, stream_ms_* = the batch on its side stream (rollout + smoothness + copies)'),
+                      stored_frames=steps)))
