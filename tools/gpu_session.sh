@@ -13,6 +13,7 @@
 #                    libserl_amd_<tag>.so; `g` = the product's code with line tables): tools/pcsamp.py collect -> <tag>/pcsamp_<lib>_<args>.json
 #   ldspmc:<lib,...> LDS counters (SQ_LDS_BANK_CONFLICT / ADDR_CONFLICT / IDX_ACTIVE / UNALIGNED_STALL, SQ_INSTS_LDS, SQ_ACTIVE_INST_LDS, SQ_WAIT_INST_LDS) of one
 #                    evaluation of the default bench on each library
+#   roleprof:<lib,...>   instruction / wait counters of one launch per library (ablation builds: tools/isa/role_profile.py)
 #   saturate[:args]  tools/bench_saturate.py (SURVEY 8d's saturating configuration)
 #   profile          tools/profile_round.sh <tag> (the round's whole profile series)
 #   py:<script.py>[,arg,...]   any script of the repo
@@ -69,6 +70,23 @@ for STEP in "$@"; do
         for k in lds sq; do python tools/pmc_summary.py $O/pmc_${k}_$L > $O/pmc_${k}_$L.json 2>> $O/err.txt; rm -rf $O/pmc_${k}_$L; done
         echo $L; tr -d '\n' < $O/pmc_lds_$L.json | cut -c1-600; echo
       done ;;
+    roleprof:*)
+      # hardware instruction counters of ONE launch (150 episodes x 2 001 steps) per library: the ablation builds of tools/sweeps/r06_ablate.json against `frz`
+      # (tools/isa/role_profile.py --pmc <tag>/roleprof.json turns the differences into instructions per role and env step)
+      echo "{" > $O/roleprof.json
+      for L in $(echo ${STEP#roleprof:} | tr ',' ' '); do
+        LIBENV=""; [ $L != default ] && LIBENV="SERL_LIB=$R/serl_amd/csrc/libserl_amd_$L.so"
+        (cd /tmp && export TMPDIR=/tmp
+         P1="python $R/tools/one_rollout.py"
+         env $LIBENV timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 -d $O/rp1_$L -o p -- $P1 > $O/rp1_$L.log 2>&1
+         env $LIBENV timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SENDMSG -d $O/rp2_$L -o p -- $P1 > $O/rp2_$L.log 2>&1
+         env $LIBENV timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS -d $O/rp3_$L -o p -- $P1 > $O/rp3_$L.log 2>&1)
+        echo "\"$L\": [" >> $O/roleprof.json
+        for k in 1 2 3; do python tools/pmc_summary.py $O/rp${k}_$L >> $O/roleprof.json 2>> $O/err.txt; [ $k != 3 ] && echo "," >> $O/roleprof.json; rm -rf $O/rp${k}_$L; done
+        echo "]," >> $O/roleprof.json
+      done
+      echo "\"episodes\": 150, \"steps_per_episode\": 2001}" >> $O/roleprof.json
+      python -c "import json; d=json.load(open('$O/roleprof.json')); print({k: round(v[0].get('SQ_INSTS_VALU', 0) / 300150) for k, v in d.items() if isinstance(v, list)})" ;;
     saturate*)
       A=$(echo ${STEP#saturate} | tr ':,' '  ')
       timeout 1500 python tools/bench_saturate.py $A > $O/saturate.jsonl 2>> $O/err.txt; cut -c1-420 $O/saturate.jsonl ;;
