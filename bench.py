@@ -147,6 +147,7 @@ def main():
     ap.add_argument('--fused', action='store_true', help='mixed workload: ONE launch of one code object (the default whenever the library takes the combination; kept for A/B scripts)')
     ap.add_argument('--no-fused', action='store_true', help='mixed workload: a launch per dynamics build side by side instead of ONE launch of one code object (A/B)')
     ap.add_argument('--strong-legs', choices=['auto', 'on', 'off'], default='auto', help='append the strong-scaling legs (pop=512, mixed pop=2048) to the line: auto = when N > 1 and no --total-pop / --pop')
+    ap.add_argument('--timeout-s', type=float, default=900.0, help='--dry-partition: the time-out the plan is checked against (the driver\'s is not known to this script; "within minutes" is the contract)')
     ap.add_argument('--dry-partition', action='store_true', help='print the member / episode blocks of every rank for --gpus N [--total-pop M | --pop P] and exit: no GPU, no launcher')
     a = ap.parse_args()
     if a.dry_partition:
@@ -163,7 +164,8 @@ def main():
                           'num_evals': ne_, 'blocks': blocks, 'covers_every_member_once': covered == list(range(total)),
                           'gather': 'one all_gather of [num_evals, ceil(pop / world), 6] f64 rows per evaluation (serl_amd/distributed.py gather_rows)',
                           'strong_scaling_legs': [dict(leg, blocks=[list(sd_.member_block(leg['total_pop'], a.gpus, r)) for r in range(a.gpus)]) for leg in strong_legs(a, a.gpus)],
-                          'strong_scaling_note': STRONG_NOTE if strong_legs(a, a.gpus) else None}))
+                          'strong_scaling_note': STRONG_NOTE if strong_legs(a, a.gpus) else None,
+                          'expected': expected_wall(a, a.gpus)}))
         return
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(a)
@@ -207,6 +209,80 @@ def main():
 STRONG_NOTE = ('`value` of this line is WEAK scaling: every GPU evaluates its own pop = 50 (150 episodes, one per CU-resident team; 106 CUs idle).  STRONG scaling of pop = 50 is '
                'flat by construction -- 150 / N episodes per GPU take the same kernel time as 150 (each episode owns a CU and is latency-bound; ceil-blocks give 7,7,7,7,7,7,7,1 members '
                'on 8 ranks) -- so the strong-scaling figures are the legs: one population of 512 (BASELINE config 4) and the mixed-fault sweep of 2 048 (config 5) sharded by member.')
+
+
+# Measured single-GPU times behind --dry-partition's expected wall time (MI355X; profiles/r05_fin_bench_*.json, refreshed by profiles/r06_*): what ONE
+# population evaluation costs on one GPU by kernel class, and what the host adds around it.  Only the order of magnitude matters: the plan must fit the
+# driver's time-out with a wide margin or say which check to drop.
+PLAN_TIMES = {
+    'serl50_one_round_ms': 109.2,          # <= CUs episodes, one per team (bench_serl50 / bench_pop64: 150 or 192 episodes x 8 001 steps)
+    'serl50_two_per_team_ms': 139.0,       # <= 2 x CUs (bench_pop128)
+    'serl50_four_per_team_ms': 172.0,      # <= 4 x CUs (bench_pop341)
+    'serl50_queue_steps_per_s': 36.6e6,    # > 4 x CUs, four per team + work queue (bench_total512)
+    'mixed_four_per_team_ms': 174.5,       # mixed sweep <= 4 x CUs in one launch (bench_mixed: 768 episodes)
+    'mixed_queue_steps_per_s': 39.9e6,     # (bench_mixed_total2048: 6 144 episodes)
+    'serl10_one_round_ms': 125.6,          # streamed actor, one per team (bench_serl10)
+    'startup_s': 12.0,                     # python + torch + HIP context + first launch of a process (driver_run_s of the default line less its steps)
+    'ref_table_s_per_episode': 2.2e-3,     # refsignals.synthetic_reference_tables on one host core (8 001 x 3 f64 per episode) + its H2D copy
+    'member_s': 0.7e-3,                    # make_population per member
+    'rendezvous_s': 6.0,                   # torch.distributed.run + RCCL communicator for N > 1
+}
+
+
+def _eval_seconds(workload, episodes, cus=256):
+    P = PLAN_TIMES
+    if episodes <= 0:
+        return 0.0
+    if workload == 'mixed':
+        return P['mixed_four_per_team_ms'] / 1e3 * max(episodes / 768.0, 0.5) if episodes <= 4 * cus else episodes * 8001 / P['mixed_queue_steps_per_s']
+    if workload == 'serl10':
+        return P['serl10_one_round_ms'] / 1e3 * -(-episodes // cus)
+    if episodes <= cus:
+        return P['serl50_one_round_ms'] / 1e3
+    if episodes <= 2 * cus:
+        return P['serl50_two_per_team_ms'] / 1e3
+    if episodes <= 4 * cus:
+        return P['serl50_four_per_team_ms'] / 1e3
+    return episodes * 8001 / P['serl50_queue_steps_per_s']
+
+
+def expected_wall(a, world):
+    """--dry-partition: what the command is expected to take on an N-GPU node, piece by piece (seconds), from PLAN_TIMES: the line itself, the
+    strong-scaling legs it appends, and rank 0's partition checks (one GPU re-evaluating all members) -- the only pieces that GROW with N."""
+    from serl_amd import distributed as sd_
+    P = PLAN_TIMES
+    pieces = []
+
+    def piece(name, workload, total_members, per_rank_members, steps, warmup, check):
+        ne = a.num_evals
+        e_rank, e_all = per_rank_members * ne, total_members * ne
+        t = dict(name=name, episodes_per_gpu=e_rank,
+                 inputs_s=round(e_rank * P['ref_table_s_per_episode'] + per_rank_members * P['member_s'], 2),
+                 timed_and_warmup_s=round((steps + warmup) * _eval_seconds(workload, e_rank), 2),
+                 host_buffer_variant_s=round(2 * _eval_seconds(workload, e_rank), 2),
+                 partition_check_s=round((e_all * P['ref_table_s_per_episode'] + total_members * P['member_s'] + _eval_seconds(workload, e_all)) if check else 0.0, 2))
+        t['total_s'] = round(t['inputs_s'] + t['timed_and_warmup_s'] + t['host_buffer_variant_s'] + t['partition_check_s'], 2)
+        pieces.append(t)
+
+    wl = WORKLOADS[a.workload]
+    check = world > 1 and not a.no_partition_check
+    if a.total_pop > 0:
+        per = max(sd_.member_block(a.total_pop, world, r)[1] - sd_.member_block(a.total_pop, world, r)[0] for r in range(world))
+        piece('line (strong: pop = %d over %d GPUs)' % (a.total_pop, world), a.workload, a.total_pop, per, a.steps, a.warmup, check)
+    else:
+        per = a.pop or wl['pop']
+        piece('line (weak: pop = %d per GPU)' % per, a.workload, per * world, per, a.steps, a.warmup, check)
+    for leg in strong_legs(a, world):
+        per = max(sd_.member_block(leg['total_pop'], world, r)[1] - sd_.member_block(leg['total_pop'], world, r)[0] for r in range(world))
+        piece('leg %s pop = %d' % (leg['workload'], leg['total_pop']), leg['workload'], leg['total_pop'], per, leg['steps'], leg['warmup'], check)
+    fixed = P['startup_s'] + (P['rendezvous_s'] if world > 1 else 0.0)
+    total = fixed + sum(t['total_s'] for t in pieces)
+    without = total - sum(t['partition_check_s'] for t in pieces)
+    return dict(pieces=pieces, startup_and_rendezvous_s=fixed, expected_wall_s=round(total, 1), expected_wall_s_with_no_partition_check=round(without, 1),
+                assumed_timeout_s=a.timeout_s, fits_timeout=bool(total < a.timeout_s),
+                advice=None if total < a.timeout_s else ('add --no-partition-check (-%.0f s)' % (total - without) if without < a.timeout_s else 'add --strong-legs off'),
+                source='bench.PLAN_TIMES: single-GPU evaluation times by kernel class and host-side rates measured on an MI355X box (profiles/r05_fin_bench_*.json); the '
+                       'CPU-baseline leg runs at N = 1 only and is not part of an N-GPU plan')
 
 
 def strong_legs(a, world):

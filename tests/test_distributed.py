@@ -192,6 +192,31 @@ def test_bench_n_gpu_command_plans_the_strong_scaling_legs():
         assert dry(*args)['strong_scaling_legs'] == []
 
 
+def test_bench_n_gpu_plan_fits_the_time_out_and_says_what_to_drop():
+    """the N = 8 command -- weak line + the two strong-scaling legs + rank 0's partition checks, the only pieces that grow with N (the
+    6 144-episode leg re-evaluated on one GPU) -- must fit a driver's time-out by the measured per-leg times (bench.PLAN_TIMES), the dry run prints the
+    expected wall time piece by piece, and --no-partition-check is the documented way out when it does not."""
+    import subprocess, json
+
+    def dry(*args):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--dry-partition'] + list(args), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])['expected']
+    e8 = dry('--gpus', '8')
+    names = [p['name'] for p in e8['pieces']]
+    assert len(names) == 3 and names[0].startswith('line (weak') and 'serl50 pop = 512' in names[1] and 'mixed pop = 2048' in names[2]
+    assert [p['episodes_per_gpu'] for p in e8['pieces']] == [150, 192, 768]
+    assert e8['fits_timeout'] and e8['expected_wall_s'] < 0.5 * e8['assumed_timeout_s'], e8          # minutes, with a factor of two to spare
+    assert e8['pieces'][2]['partition_check_s'] > e8['pieces'][0]['partition_check_s'] > 0          # the 6 144-episode check is the largest single piece that N adds
+    assert abs(e8['expected_wall_s'] - e8['startup_and_rendezvous_s'] - sum(p['total_s'] for p in e8['pieces'])) < 0.2
+    e8n = dry('--gpus', '8', '--no-partition-check')
+    assert all(p['partition_check_s'] == 0 for p in e8n['pieces']) and abs(e8n['expected_wall_s'] - e8['expected_wall_s_with_no_partition_check']) < 0.2
+    tight = dry('--gpus', '8', '--timeout-s', str(e8['expected_wall_s'] - 1))
+    assert not tight['fits_timeout'] and 'no-partition-check' in tight['advice']
+    e1 = dry('--gpus', '1')
+    assert len(e1['pieces']) == 1 and e1['pieces'][0]['partition_check_s'] == 0 and e1['expected_wall_s'] < e8['expected_wall_s']
+
+
 def test_member_blocks_cover_population():
     from serl_amd import distributed as sd
     for pop in (1, 5, 50, 512, 2048):
