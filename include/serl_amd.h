@@ -206,6 +206,8 @@ int serl_ctx_load_build(serl_ctx *ctx, int slot, const serl_build_desc *build);
  *   SERL_WAVES_PER_BLOCK=n                   wavefronts per workgroup of the one-wavefront kernels
  *   SERL_PROFILE=1                           cycle counters for serl_debug_profile
  *   SERL_SPLIT_ACTOR=1                       one-episode teams with a streamed actor (hidden > 64): two actor wavefronts share the forward pass
+ *   SERL_REMOTE_ACTOR=0                      one-episode teams with a streamed actor: the actor stays on the team's CU (default 1: a workgroup of its own on another CU
+ *                                            while two workgroups per episode fit the GPU at once -- serl_rollout_teamr_kernel_<variant>)
  *   SERL_JITTER_SEED=n, SERL_JITTER_SITES=m  acted on only by the TEST-ONLY stress build of the team kernels (libserl_amd_jitter.so:
  *                                            poisoned LDS blackboards, seeded pauses around every hand-over; the product ignores them;
  *                                            a development build -DSERL_DEV_ROLE_MAP=1 reads SERL_JITTER_SITES as the role <-> wavefront map of
@@ -253,7 +255,8 @@ enum serl_kernel_family { SERL_FAMILY_NONE = 0, SERL_FAMILY_TEAM = 1 /* eight wa
                           SERL_FAMILY_TEAM2 = 5 /* two episodes per team */, SERL_FAMILY_TEAM2S = 6 /* ... six team + two streaming actor wavefronts */,
                           SERL_FAMILY_TEAM4 = 7 /* four episodes per team */, SERL_FAMILY_TEAM4_MIXED = 8 /* ... several code variants in one launch */,
                           SERL_FAMILY_HALF = 9 /* one wavefront = two episodes */, SERL_FAMILY_WAVE = 10 /* one wavefront = one episode */,
-                          SERL_FAMILY_WAVEX = 11 /* ... other env configurations */, SERL_FAMILY_LANE = 12 /* one lane = one episode */ };
+                          SERL_FAMILY_WAVEX = 11 /* ... other env configurations */, SERL_FAMILY_LANE = 12 /* one lane = one episode */,
+                          SERL_FAMILY_TEAMR = 13 /* eight wavefronts = one episode, its streamed actor (two wavefronts) in a workgroup of its own on another CU */ };
 int serl_last_rollout_info(serl_ctx *ctx, int32_t out[8]);
 
 /* Duration (ms) of the most recent serl_rollout kernel on its stream, measured with HIP events

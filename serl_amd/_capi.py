@@ -54,7 +54,7 @@ class ReplayJob(ctypes.Structure):
 KERNEL_HINTS = {None: 0, 'auto': 0, 'team': 1, 'wave': 2, 'half': 3, 'team2': 4, 'team4': 5}
 ABI_VERSION = 8
 # serl_last_rollout_info out[0] (enum serl_kernel_family)
-FAMILIES = {0: None, 1: 'team', 2: 'teams', 3: 'teams2', 4: 'teamx', 5: 'team2', 6: 'team2s', 7: 'team4', 8: 'team4_mixed', 9: 'half', 10: 'wave', 11: 'wavex', 12: 'lane'}
+FAMILIES = {0: None, 1: 'team', 2: 'teams', 3: 'teams2', 4: 'teamx', 5: 'team2', 6: 'team2s', 7: 'team4', 8: 'team4_mixed', 9: 'half', 10: 'wave', 11: 'wavex', 12: 'lane', 13: 'teamr'}
 
 
 def expected_layout():

@@ -176,9 +176,14 @@ def spec_from_state_dict(sd, activation):
 
 def pack_actor(actor_or_sd):
     """Flat f32 row in state_dict order (W0 b0 {Wl bl gamma beta}xL Wo bo) as the kernel expects."""
-    sd = actor_or_sd if isinstance(actor_or_sd, dict) else (
-        actor_or_sd.actor.state_dict() if hasattr(actor_or_sd, 'actor') else actor_or_sd.state_dict())
-    return torch.cat([v.detach().reshape(-1).to(torch.float32).cpu() for v in sd.values()])
+    if isinstance(actor_or_sd, dict):
+        vals = actor_or_sd.values()
+    else:
+        m = actor_or_sd.actor if hasattr(actor_or_sd, 'actor') else actor_or_sd
+        # a module without buffers: parameters() walks the tensors in state_dict order (own parameters, then the children's) without building the
+        # dictionary and running its hooks -- 0.02 ms per actor instead of 0.09 (a generation packs pop + 1 of them)
+        vals = m.parameters() if next(m.buffers(), None) is None else m.state_dict().values()
+    return torch.cat([v.detach().reshape(-1) for v in vals]).to(torch.float32).cpu()
 
 
 def pad_rows(w):

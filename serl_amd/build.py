@@ -16,6 +16,7 @@ UNITS = ['serl_capi.hip', 'serl_ga.hip', 'serl_metrics.hip', 'serl_distill.hip',
          'rollout_team2_nominal.hip', 'rollout_team2_ice.hip', 'rollout_team2_cg_timed.hip', 'rollout_team2_gust.hip', 'rollout_team2_test.hip',
          'rollout_team4_mixed.hip', 'rollout_team4_nominal.hip', 'rollout_team4_ice.hip', 'rollout_team4_cg_timed.hip', 'rollout_team4_gust.hip', 'rollout_team4_test.hip',
          'rollout_teams2_nominal.hip', 'rollout_teams2_ice.hip', 'rollout_teams2_cg_timed.hip', 'rollout_teams2_gust.hip', 'rollout_teams2_test.hip',
+         'rollout_teamr_nominal.hip', 'rollout_teamr_ice.hip', 'rollout_teamr_cg_timed.hip', 'rollout_teamr_gust.hip', 'rollout_teamr_test.hip',
          'rollout_team2s_nominal.hip', 'rollout_team2s_ice.hip', 'rollout_team2s_cg_timed.hip', 'rollout_team2s_gust.hip', 'rollout_team2s_test.hip',
          'rollout_half_nominal.hip', 'rollout_half_ice.hip', 'rollout_half_cg_timed.hip', 'rollout_half_gust.hip', 'rollout_half_test.hip']
 # -ffp-contract=off: the IEEE-754 operation order of the reference binary is part of the contract (no FMA fusion).

@@ -10,6 +10,7 @@
 //   envs/{be,jr,sa,se}/citation.py:71-79 (actuator faults as a per-episode row)
 // Included once per dynamics code variant with DYN_STEP defined.
 #pragma once
+#include <type_traits>
 #include "../../include/serl_amd.h"
 #ifndef CITW_T            // phase-profile marks (citation_wave.h, -DCITW_PROFILE builds); no-ops elsewhere
 #define CITW_T(k) ((void)0)
@@ -27,7 +28,16 @@ struct RolloutArgs {
   int32_t *queue;                     // multi-episode team kernels: device counter of the episodes handed out beyond the first one of every lane group
   int32_t q0;                         // ... the first episode of the queue (episodes [q0, e_end) are taken as lane groups finish theirs)
   uint32_t jitter, jitter_sites;      // hand-over stress builds only (citation_wave.h, -DCITW_JITTER): seed of the pseudo-random pauses (0 = none), classes of sites that pause
+  void *mail;                         // remote-actor team kernels (rollout_team.inc SERL_TEAM_REMOTE): device [episodes of the launch] SerlMail, zeroed per launch
 };
+
+// The mailbox of ONE episode between its team workgroup and its actor workgroup on another CU (serl_rollout_teamr_kernel_<v>): the state x_k travels
+// one way behind xseq = k + 2, the command of env step k + 1 the other way behind aseq = k + 2 (device-scope release / acquire; a cache line each)
+struct SerlMail {
+  unsigned xseq, pad0; double x[12]; unsigned pad1[6];
+  unsigned aseq, pad2; double cmd[3]; unsigned pad3[24];
+};
+static_assert(sizeof(SerlMail) == 256, "two cache lines");
 
 #include "serl_kregs.h"
 #define DET_FN __device__ __forceinline__
@@ -188,6 +198,15 @@ struct SerlNoSync { __device__ __forceinline__ void operator()(int, int) const {
 #else
 #define SERL_CREDIT_JIT(c) ((void)0)
 #endif
+// ... and the credit of an actor wavefront that shares no workgroup with a team (the remote-actor kernels): nothing to pay
+struct SerlNoCredit {
+  int done, per_step;
+  unsigned salt = 0;
+  bool defer_last = false;
+  __device__ __forceinline__ void start(int) {}
+  __device__ __forceinline__ void upto(int) {}
+  __device__ __forceinline__ void operator()(int, int) {}
+};
 struct SerlBarrierCredit {
   int done, per_step;
 #if defined(CITW_JITTER) && CITW_JITTER
@@ -609,6 +628,121 @@ static __device__ void serl_actor_forward_split(const serl_rollout_desc &dd, con
   }
   // (the rest of the step's barriers is the caller's: part 0 hands the action over first)
 #undef SERL_ISSUE2
+}
+
+// ---- one forward pass over the FOUR wavefronts of a workgroup that has a CU to itself (round 6: the remote actor of serl_rollout_teamr_kernel_<v>) --------
+// Two lanes per hidden row: the first runs the partial sums p0, p1 of the row's dot product (columns 4 m, 4 m + 1 -- one 8-byte load of the row, one
+// v_pk_fma_f32 per m), the second p2, p3 (columns 4 m + 2, 4 m + 3); (p0 + p1) and (p2 + p3) are formed where they are, the first lane adds them and the
+// bias: the arithmetic of include/serl_amd.h -- four interleaved fma partial sums over ascending j, bias + ((p0 + p1) + (p2 + p3)) -- with a dependent
+// chain of H / 4 instead of H operations.  H = 72: 144 lanes, 96: 192, 128: 256.  A row's value goes to LDS (accbuf, double-buffered by layer), ONE
+// workgroup barrier per layer, then every wavefront holds the whole layer in the lone wavefront's layout (rows 0 .. 63 on the lanes, rows 64 .. on the first
+// lanes) and runs its LayerNorm / activation code on it redundantly -- same sums in the same order on the same values as serl_actor_forward_wave (= the
+// oracle) -- and writes the layer into a row of its OWN (hrow), from which its lanes read the next layer's columns as broadcasts.  Weights come straight
+// from L2 (natural layout), the next layer's row halves are in flight while the current one is summed.  wave: 0 .. 3; act_out is written on wave 0 only.
+template <int H>
+static __device__ void serl_actor_forward_cu(const serl_rollout_desc &dd, const float *w_generic, const float obs[7], float act_out[3],
+                                             const int wave, float (*accbuf)[128], float *hrow /* this wavefront's own 128 floats */)
+{
+  static_assert(H % 4 == 0 && H > 64 && H <= 128, "two lanes per row on four wavefronts");
+  constexpr int M = H / 4;
+  typedef const __attribute__((address_space(1))) serl_v2f *gptr2;
+  const int L = __builtin_amdgcn_readfirstlane(dd.num_layers), act = __builtin_amdgcn_readfirstlane(dd.activation);
+  serl_gptr w = (serl_gptr)w_generic;
+  const int lane = threadIdx.x & 63;
+  const int gl = wave * 64 + lane, r = gl >> 1, c2 = gl & 1;
+  const bool mine = r < H;
+  const int rr = mine ? r : H - 1;                                  // my row (clamped)
+  const int ro = r < 3 ? r : 2;                                     // my output-layer row (clamped)
+  const int i0 = lane, i1 = lane + 64 < H ? lane + 64 : H - 1;      // rows of the exchanged layout
+  constexpr int Ha = 64, Hb = H - 64;
+  const size_t lstride = (size_t)H * H + 3 * (size_t)H;
+  serl_gptr hid = w + (size_t)H * 7 + H;
+  serl_gptr outl = hid + (size_t)L * lstride;
+  serl_v2f nw[M];                                                    // the next layer's half row in flight
+  float nbias = 0.0f, ngm0 = 0.0f, ngm1 = 0.0f, nbt0 = 0.0f, nbt1 = 0.0f;
+  auto issue = [&](const int l) {                                   // l < L: hidden layer l; l == L: the output layer
+    serl_gptr row = l < L ? hid + (size_t)l * lstride + (size_t)rr * H : outl + (size_t)ro * H;
+#pragma unroll
+    for (int m = 0; m < M; ++m) nw[m] = *(gptr2)(row + 4 * m + 2 * c2);
+    if (l < L) {
+      serl_gptr bl = hid + (size_t)l * lstride + (size_t)H * H;
+      nbias = bl[rr]; ngm0 = bl[H + i0]; nbt0 = bl[2 * H + i0]; ngm1 = bl[H + i1]; nbt1 = bl[2 * H + i1];
+    } else {
+      nbias = (outl + (size_t)3 * H)[ro];
+    }
+  };
+  // all my rows' values -> LDS, one barrier, the whole layer back in the lone wavefront's layout
+  auto exchange = [&](const int layer, const float v, float &a0, float &a1) {
+    float *buf = accbuf[layer & 1];
+    if (mine && c2 == 0) buf[r] = v;
+    __syncthreads();                                                // (the four actor wavefronts are the workgroup's only live ones)
+    a0 = buf[i0];
+    a1 = buf[i1];
+  };
+  auto publish = [&](const float h0a, const float h0b) {            // the layer into this wavefront's own row (read back as broadcasts)
+    hrow[i0] = h0a;
+    if (lane < Hb) hrow[lane + 64] = h0b;
+    SERL_WAVE_FENCE();
+  };
+  // ---- input layer: Linear(7, H) act; p0 = w0 o0 (+ w4 o4), p1 = w1 o1 (+ w5 o5) on the first lane, p2 = w2 o2 (+ w6 o6), p3 = w3 o3 on the second
+  float h0a, h0b;
+  {
+    serl_gptr W0 = w + (size_t)rr * 7, b0 = w + (size_t)H * 7;
+    const float wa = W0[2 * c2], wb = W0[2 * c2 + 1], wc = W0[4 + 2 * c2], wd = c2 ? 0.0f : W0[5];
+    const float bias = b0[rr];
+    issue(0);
+    const float oa = c2 ? obs[2] : obs[0], ob = c2 ? obs[3] : obs[1], oc = c2 ? obs[6] : obs[4];
+    float pa = __builtin_fmaf(wa, oa, 0.0f), pb = __builtin_fmaf(wb, ob, 0.0f);
+    pa = __builtin_fmaf(wc, oc, pa);
+    if (!c2) pb = __builtin_fmaf(wd, obs[5], pb);
+    const float half = pa + pb;                                     // (p0 + p1) on the first lane, (p2 + p3) on the second
+    const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(half), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]: the neighbour's
+    const float acc = serl_act(bias + (half + other), act);         // (first lane: (p0 + p1) + (p2 + p3))
+    exchange(0, acc, h0a, h0b);
+    publish(h0a, h0b);
+  }
+  const unsigned hb = serl_lds_row_base(hrow);
+  typedef const __attribute__((address_space(3))) serl_v2f *lrow2;
+  for (int l = 0; l <= L; ++l) {
+    serl_v2f wv[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) wv[m] = nw[m];
+    const float bias = nbias, gm0 = ngm0, gm1 = ngm1, bt0 = nbt0, bt1 = nbt1;
+    if (l < L) issue(l + 1);
+    serl_v2f p = {0.0f, 0.0f};
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const serl_v2f hv = *(lrow2)(unsigned long long)(hb + 4u * (unsigned)(4 * m + 2 * c2));
+      p = __builtin_elementwise_fma(wv[m], hv, p);
+    }
+    const float half = p.x + p.y;
+    const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(half), 0xB1, 0xF, 0xF, true));
+    const float accm = bias + (half + other);
+    if (l < L) {
+      float acc0, acc1;
+      exchange(l + 1, accm, acc0, acc1);
+      const float mean = serl_tree_sum_rt(acc0, acc1, Ha, Hb, lane) / (float)H;
+      const float d0 = acc0 - mean, d1 = acc1 - mean;
+      const float var = serl_tree_sum_rt(d0 * d0, d1 * d1, Ha, Hb, lane);
+      const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
+      h0a = serl_act(gm0 * d0 / den + bt0, act);
+      h0b = serl_act(gm1 * d1 / den + bt1, act);
+      publish(h0a, h0b);
+    } else if (wave == 0) {
+      const float t = det_tanhf(accm);                              // rows 0, 1, 2 of the output layer sit on lanes 0, 2, 4 of wavefront 0
+      for (int i = 0; i < 3; ++i) act_out[i] = serl_bcast(t, 2 * i);
+    }
+  }
+}
+
+static __device__ __forceinline__ bool serl_cu_actor_ok(const serl_rollout_desc &dd) { return dd.hidden == 72 || dd.hidden == 96 || dd.hidden == 128; }
+static __device__ __forceinline__ void serl_actor_forward_cu_any(const serl_rollout_desc &dd, const float *w, const float obs[7], float act_out[3],
+                                                                 const int wave, float (*accbuf)[128], float *hrow)
+{
+  const int H = __builtin_amdgcn_readfirstlane(dd.hidden);
+  if (H == 72) serl_actor_forward_cu<72>(dd, w, obs, act_out, wave, accbuf, hrow);
+  else if (H == 96) serl_actor_forward_cu<96>(dd, w, obs, act_out, wave, accbuf, hrow);
+  else serl_actor_forward_cu<128>(dd, w, obs, act_out, wave, accbuf, hrow);
 }
 
 // Shape-specialised forward for H <= 64 (one row per lane, H a multiple of 4): every loop bound is a compile-time

@@ -33,7 +33,8 @@ SERL_DECL_WAVE(nominal) SERL_DECL_WAVE(ice) SERL_DECL_WAVE(cg_timed) SERL_DECL_W
 SERL_DECL_TEAM(nominal) SERL_DECL_TEAM(ice) SERL_DECL_TEAM(cg_timed) SERL_DECL_TEAM(gust) SERL_DECL_TEAM(test)
 // ... with one forward pass over two actor wavefronts (rollout_teams2_<v>.hip: hidden > 64)
 #include "serl_mixed.h"
-#define SERL_DECL_TEAMS2(v) void serl_launch_rollout_teams2_##v(const RolloutArgs &a, int grid, hipStream_t stream);
+#define SERL_DECL_TEAMS2(v) void serl_launch_rollout_teams2_##v(const RolloutArgs &a, int grid, hipStream_t stream); \
+                            void serl_launch_rollout_teamr_##v(const RolloutArgs &a, int grid, hipStream_t stream);
 SERL_DECL_TEAMS2(nominal) SERL_DECL_TEAMS2(ice) SERL_DECL_TEAMS2(cg_timed) SERL_DECL_TEAMS2(gust) SERL_DECL_TEAMS2(test)
 
 // two episodes per wavefront (rollout_half.inc): beyond one wavefront per SIMD
@@ -136,6 +137,27 @@ static bool serl_use_team(const serl_ctx *c, int hint, int episodes)
 
 // (rollout_device.h: serl_lds_actor_ok) the actor shape whose weights live in LDS for the episode
 static bool serl_lds_actor_shape(const serl_rollout_desc &d) { return d.hidden == 32 && d.num_layers <= 3 && d.state_dim == 7 && d.action_dim == 3; }
+
+// Round 6: streamed actors (hidden 65 .. 128: SERL10's 72, the TD3 actor's 96) of the attitude task with the actor in a workgroup of its own on another CU
+// (rollout_teamr_<v>.hip): two workgroups per episode, pairs (b, b + 8) of a group of sixteen.  Only while every workgroup of the launch -- and of the launches it
+// was told about -- can be resident at once: a team spins on its partner's mailbox.  0 = not eligible, else the grid.
+static int serl_remote_actor_grid(const serl_ctx *c, const serl_rollout_desc *d, int together)
+{
+  if (!c->env_remote_actor || (d->hidden != 72 && d->hidden != 96 && d->hidden != 128) || d->state_dim != 7 || d->action_dim != 3) return 0;      // (rollout_device.h serl_cu_actor_ok)
+  const int grid = 16 * ((d->n_episodes + 7) / 8), all = 16 * ((together + 7) / 8);
+  return all <= c->num_cus ? grid : 0;
+}
+
+static void serl_launch_rollout_teamr(int code, const RolloutArgs &a, int grid, hipStream_t stream)
+{
+  switch (code) {
+    case SERL_DYN_NOMINAL: serl_launch_rollout_teamr_nominal(a, grid, stream); break;
+    case SERL_DYN_ICE: serl_launch_rollout_teamr_ice(a, grid, stream); break;
+    case SERL_DYN_CG_TIMED: serl_launch_rollout_teamr_cg_timed(a, grid, stream); break;
+    case SERL_DYN_GUST: serl_launch_rollout_teamr_gust(a, grid, stream); break;
+    default: serl_launch_rollout_teamr_test(a, grid, stream); break;
+  }
+}
 
 static void serl_launch_rollout_team(int code, const RolloutArgs &a, int grid, hipStream_t stream, bool split_actor = false)
 {
@@ -325,6 +347,7 @@ int serl_ctx_create(int device, serl_ctx **out)
     c->env_waves_per_block = (e = getenv("SERL_WAVES_PER_BLOCK")) ? atoi(e) : -1;
     c->env_profile = getenv("SERL_PROFILE") != nullptr;
     c->env_split_actor = (e = getenv("SERL_SPLIT_ACTOR")) ? atoi(e) : 0;
+    c->env_remote_actor = (e = getenv("SERL_REMOTE_ACTOR")) ? atoi(e) : 1;
     c->env_mixed_place = (e = getenv("SERL_MIXED_PLACE")) ? atoi(e) : SERL_MIXED_PLACE_DEFAULT;
     c->env_jitter = (e = getenv("SERL_JITTER_SEED")) ? (unsigned)strtoul(e, nullptr, 0) : 0u;
     c->env_jitter_sites = (e = getenv("SERL_JITTER_SITES")) ? (unsigned)strtoul(e, nullptr, 0) : ~0u;
@@ -341,6 +364,7 @@ int serl_ctx_destroy(serl_ctx *c)
   if (!c) return SERL_OK;
   (void)hipSetDevice(c->device);
   for (auto &s : c->slots) if (s.blob) (void)hipFree(s.blob);
+  if (c->mail) (void)hipFree(c->mail);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->prof) (void)hipFree(c->prof);
@@ -480,6 +504,23 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     a.lanes = 1;
     a.block = 128;
     if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
+    const int rgrid = serl_remote_actor_grid(c, d, together);
+    if (rgrid > 0) {
+      // mailboxes of this launch: a region of the ring, zeroed on the launch's stream in front of it
+      const size_t region = (size_t)c->num_cus * sizeof(SerlMail);
+      if (!c->mail) HIP_TRY(hipMalloc(&c->mail, SERL_MAIL_REGIONS * region));
+      a.mail = (char *)c->mail + (size_t)c->mail_next * region;
+      c->mail_next = (c->mail_next + 1) % SERL_MAIL_REGIONS;
+      HIP_TRY(hipMemsetAsync(a.mail, 0, (size_t)d->n_episodes * sizeof(SerlMail), stream));
+      a.block = 512;
+      if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));      // (re-recorded behind the memset: the kernel alone is timed)
+      serl_launch_rollout_teamr(s.code, a, rgrid, stream);
+      HIP_TRY(hipGetLastError());
+      serl_note_launch(c, SERL_FAMILY_TEAMR, rgrid, 1, false, 4, true, 1, s.code);
+      if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
+      c->timed = timed;
+      return SERL_OK;
+    }
     serl_launch_rollout_team(s.code, a, d->n_episodes, stream, c->env_split_actor != 0);
     HIP_TRY(hipGetLastError());
     {

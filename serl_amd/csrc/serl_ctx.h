@@ -8,6 +8,7 @@
 #define SERL_MAX_SLOTS 16
 #define SERL_QUEUE_COUNTERS 64
 #define SERL_MIXED_PLACE_DEFAULT 2
+#define SERL_MAIL_REGIONS 8              // mailbox regions of remote-actor launches in flight (a ring, like the queue counters)
 #define SERL_MIXED_STATES 8             // placement states of serl_rollout_multi launches in flight (a ring, like the queue counters)
 
 int serl_fail(int code, const std::string &msg);      // records the thread-local message of serl_last_error()
@@ -47,5 +48,8 @@ struct serl_ctx {
   unsigned long long *prof = nullptr;   // device [32], allocated when SERL_PROFILE=1
   int32_t *queue = nullptr;             // device [SERL_QUEUE_COUNTERS]: work-queue counters of the multi-episode team kernels, one per LAUNCH (a ring)
   int queue_next = 0;
+  int env_remote_actor = 1;             // SERL_REMOTE_ACTOR=0: streamed actors of one-episode teams stay on the team's CU (rollout_team_<v>.hip serl_rollout_teams_kernel_; A/B)
+  void *mail = nullptr;                 // device [SERL_MAIL_REGIONS][num_cus] SerlMail: team <-> remote actor workgroup (rollout_teamr_<v>.hip)
+  int mail_next = 0;
   int32_t last_info[8] = {};            // serl_last_rollout_info: what the most recent rollout call launched (family, workgroups, episodes per team, queue, actor wavefronts, streamed, launches, code)
 };

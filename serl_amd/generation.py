@@ -88,7 +88,8 @@ def evaluate_generation(pop: Sequence, rl_agent=None, *, args, mode='nominal', t
     ne = int(args.num_evals)
     actors = [_actor_of(a) for a in pop]
     for a in actors:
-        a.eval()                                            # agent.py:83
+        if a.training:
+            a.eval()                                        # agent.py:83  (Module.eval() walks every submodule: skipped when the flag is down already)
     n_pop = len(actors)
     if n_pop == 0 and rl_agent is None:
         # (evaluate_generation_sharded: a rank whose member block is empty and no RL episode to fly -- nothing to launch)

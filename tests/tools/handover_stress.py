@@ -35,7 +35,8 @@ def cases(cus):
     """name -> (actor tag, kernel hint, episodes): every kernel family of rollout_team.inc / rollout_team_half.inc"""
     return {
         'team': ('serl50', 'team', 12),                # seven team wavefronts + the actor wavefront, weights in LDS
-        'teams': ('serl10', 'team', 6),                # ... the actor streams its weights
+        'teamr': ('serl10', 'team', 6),                # ... the streamed actor in a workgroup of its own on another CU: mailboxes in global memory, a courier wavefront (rollout_teamr_<v>.hip)
+        'teams': ('serl10', 'team', 6),                # ... the actor streams its weights on the team's CU (SERL_REMOTE_ACTOR=0)
         'teams_split': ('serl10', 'team', 6),          # ... on TWO actor wavefronts that share the forward pass (SERL_SPLIT_ACTOR=1, rollout_teams2_<v>.hip)
         'team2': ('serl50', 'team2', 21),              # two episodes per team (an odd count: one lane group stays empty)
         'team2s': ('serl10', 'team2', 11),             # six team wavefronts + two streaming actor wavefronts
@@ -65,18 +66,25 @@ def main():
     for seed in seeds:
         os.environ['SERL_JITTER_SEED'] = str(seed)          # read by serl_ctx_create
         os.environ['SERL_SPLIT_ACTOR'] = '0'
+        os.environ['SERL_REMOTE_ACTOR'] = '1'
         eng = serl_amd.RolloutEngine(0)
+        os.environ['SERL_REMOTE_ACTOR'] = '0'
+        eng_same = serl_amd.RolloutEngine(0)
         os.environ['SERL_SPLIT_ACTOR'] = '1'
         eng_split = serl_amd.RolloutEngine(0)
-        engines = (eng, eng_split)
+        os.environ['SERL_REMOTE_ACTOR'] = '1'
+        engines = (eng, eng_split, eng_same)
+        want = {'team': 'team', 'teamr': 'teamr', 'teams': 'teams', 'teams_split': 'teams2', 'team2': 'team2', 'team2s': 'team2s', 'team4': 'team4', 'queue': 'team4'}
         for name, case in cases(cus).items():
             tag, kern, n = case
-            eng = engines[1] if name == 'teams_split' else engines[0]
+            eng = engines[1] if name == 'teams_split' else engines[2] if name == 'teams' else engines[0]
             w, moe, ref, tick0 = inputs(name, case, build)
             n_ = NET[tag]
             spec = serl_amd.NetSpec(n_['state_dim'], n_['action_dim'], n_['hidden'], n_['num_layers'], n_['activation'])
             eng.kernel_hint = kern
             r = eng.rollout(torch.from_numpy(w), spec, moe, ref, build=build, t_max=T_MAX, tick0=tick0)
+            fam = eng.last_rollout_info()['family']
+            assert fam == want[name], 'case %s should run kernel family %s, the library launched %s' % (name, want[name], fam)
             for key in ('fitness', 'length_steps', 'cost_steps'):
                 out['%s_%d_%s' % (name, seed, key)] = r[key].cpu().numpy()
             print(build, name, 'seed', seed, 'kernel ms %.1f' % eng.last_kernel_ms, 'nan', int(np.isnan(out['%s_%d_fitness' % (name, seed)]).sum()),
