@@ -81,9 +81,20 @@ def cpu_port(w, hidden, ref, moe, faults_of=None, build_of=None):
         fit[idx], ls[idx] = o['fitness'], o['length_steps']
     dt = time.perf_counter() - t0
     steps = int(ls.sum())
+    # ... and the flavour that is PINNED to the reference binary (glibc libm; tests/test_oracle_dynamics.py): the same-libm flavour shares sin / cos / tan /
+    # pow / atan with the kernels, so 0.0 against it says "GPU == its own restatement"; the distance to the pinned flavour is the second claim of the line
+    # (a sample of the episodes, untimed)
+    pick = np.arange(0, E, max(1, E // 48))[:48]
+    fit_pinned = np.zeros(len(pick))
+    for b, idx in groups.items():
+        sel = np.array([i for i in pick if i in set(idx.tolist())], dtype=int)
+        if len(sel):
+            o = R.rollout(w, net, moe[sel], ref[sel], t_max=80.0, threads=cores, short_libm=False, **({} if b is None else dict(build=b, faults=[faults_of[e] for e in sel])))
+            fit_pinned[np.searchsorted(pick, sel)] = o['fitness']
     return dict(value=steps / dt, unit='env-steps/s', cores=cores, kind='port',
                 sample='all %d episodes (8001 steps each) of the same workload, C restatement '
-                       '(oracle/rollout_ref.c, same-libm flavour) on %d threads, %.1f s wall' % (E, cores, dt)), fit, ls
+                       '(oracle/rollout_ref.c, same-libm flavour) on %d threads, %.1f s wall' % (E, cores, dt),
+                pinned_sample=(pick.tolist(), fit_pinned.tolist())), fit, ls
 
 
 def cpu_baseline(w, hidden, ref, moe, faults_of=None, build_of=None):
@@ -329,6 +340,7 @@ def measure(a, ctx):
     modes = [MIXED_MODES[(lo * ne + e) % 6] for e in range(E)] if mixed else None
 
     pending = []      # (all-episodes-full flag, action traces) of speculative smoothness passes not yet confirmed
+    placements = []   # mixed workload: how every one-launch sweep placed its workgroups (PopResult.mixed_placement)
 
     def evaluate(wd, refd, moe_, n_members, modes_=None):
         """one population evaluation on this rank -> (rows f64 [ne, members, ROW] on the device, length_steps, fitness)"""
@@ -349,6 +361,7 @@ def measure(a, ctx):
             tod = lambda x: torch.as_tensor(np.ascontiguousarray(x.T).reshape(-1), device=dev)
             fit, sm, lt, cs = tod(r.returns), tod(r.smoothness), tod(r.length_t), tod(r.cost_steps).double()
             ls = tod(r.length_steps)
+            placements.append(r.mixed_placement)
         rows = torch.stack([fit, fit, sm, lt, ls.double(), cs], -1)
         return rows.view(n_members, ne, sd.ROW).transpose(0, 1).contiguous(), ls, fit
 
@@ -500,6 +513,8 @@ def measure(a, ctx):
         'value_incl_h2d_of_inputs': value_host,
         'rccl': rccl,
     }
+    if mixed and placements:
+        res['mixed_placement'] = placements[-1]      # (decision 1 = census of the CU pairs; 2 = tickets: shared GPU or another pair mapping, ~10 % slower; None = a launch per build)
     res.update(res_extra)
     if not a.no_cpu_baseline and world == 1:          # (the contract: the CPU baseline leg runs on rank 0 at N = 1 only)
         build_of = faults_of = None
@@ -512,6 +527,13 @@ def measure(a, ctx):
         rel = np.abs(fit_gpu - fit_cpu) / np.abs(fit_cpu)
         res['parity_vs_cpu_port'] = {'max_rel_fitness': float(rel.max()), 'episodes_bit_identical': int((fit_gpu == fit_cpu).sum()), 'episodes_checked': int(n_chk),
                                      'lengths_equal': bool((ls.cpu().numpy()[:n_chk] == ls_cpu).all())}
+        port_ = cb.get('port', cb)
+        if 'pinned_sample' in port_:
+            pick_, fp_ = port_.pop('pinned_sample')
+            fg_ = fit.cpu().numpy()[np.asarray(pick_, dtype=int)]
+            res['parity_vs_cpu_port']['max_rel_fitness_vs_pinned_oracle'] = float(np.max(np.abs(fg_ - np.asarray(fp_)) / np.abs(np.asarray(fp_))))
+            res['parity_vs_cpu_port']['pinned_oracle_note'] = ('%d episodes against the oracle flavour that is bit-identical to the reference binary (glibc libm); the 0.0 above is against the '
+                                                              'same-libm flavour, which shares sin / cos / tan / pow / atan with the kernels' % len(pick_))
     return res
 
 

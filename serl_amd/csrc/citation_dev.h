@@ -18,7 +18,9 @@
 #include <stdint.h>
 #include "citation_libm.h"
 
+#ifndef CIT_MAX_NB
 #define CIT_MAX_NB 648
+#endif
 #define CIT_SINCOS(x, s, c_) citw_sincos((x), (s), (c_))
 #include "citation_leaves.h"
 

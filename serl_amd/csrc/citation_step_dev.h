@@ -10,7 +10,10 @@
 #if !defined(CIT_MODEL) || !defined(CIT_DERIV) || !defined(CIT_STEP)
 #error "define CIT_MODEL, CIT_DERIV and CIT_STEP"
 #endif
-static __device__ __noinline__ void CIT_STEP(CitCtx *gc, const double *cmd_in, double *out_arg)
+#ifndef CIT_STEP_ATTR
+#define CIT_STEP_ATTR __noinline__
+#endif
+static __device__ CIT_STEP_ATTR void CIT_STEP(CitCtx *gc, const double *cmd_in, double *out_arg)
 {
   CitCtx lc;
   double y[19], f[6][19], cmd[10], out[12];

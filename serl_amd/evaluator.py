@@ -38,6 +38,8 @@ class PopResult:
     rewards: Optional[torch.Tensor] = None     # f64 [E, T]
     transitions: Optional[torch.Tensor] = None  # f32 [E, T, 20]
     episode_member: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    mixed_placement: Optional[dict] = None     # a mixed-fault sweep flown as ONE launch: how its workgroups were placed (RolloutEngine.mixed_placement:
+                                               # decision 1 = census of the CU pairs, 2 = tickets -- the GPU was shared or the pair mapping collided --, 0 = blockIdx ranges)
 
 
 class RolloutEngine:
@@ -414,7 +416,17 @@ def evaluate_pop(actors, *, mode='nominal', num_evals=3, refs=None, t_max=80, sm
     sh = lambda a: np.ascontiguousarray(a.reshape(pop, num_evals).T)
     fitness = sh(fit)
     pop_fitness = np.mean(fitness, axis=0)
-    return PopResult(fitness=fitness, returns=sh(ret), smoothness=sh(sm), length_steps=sh(ls),
+    placement = None
+    if use_multi:
+        # how the one-launch sweep placed its workgroups (the results are back: the launch is over).  Tickets instead of the census -- a GPU shared with
+        # another launch, or a device whose CU-pair mapping differs from the one the census assumes -- cost ~10 %: said once, not silently
+        placement = engine.mixed_placement()
+        if placement['decision'] == 2 and not getattr(engine, '_warned_tickets', False):
+            import warnings
+            engine._warned_tickets = True
+            warnings.warn('serl_amd: the mixed-fault sweep placed its workgroups by tickets, not by the census of CU pairs (%s): the GPU was shared with '
+                          'another launch or the instruction-cache pairs of this device are not (1,2)(3,4)(5,6)(7,8); expect ~10 %% less throughput' % placement)
+    return PopResult(mixed_placement=placement, fitness=fitness, returns=sh(ret), smoothness=sh(sm), length_steps=sh(ls),
                      length_t=sh(out['length_t'].cpu().numpy()), cost_steps=sh(out['cost_steps'].cpu().numpy()),
                      pop_fitness=pop_fitness, champion=int(np.argmax(pop_fitness)), worst=int(np.argmin(pop_fitness)),
                      kernel_ms=engine.last_kernel_ms,
