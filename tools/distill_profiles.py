@@ -4,10 +4,10 @@
 import json, shutil, sys
 tag, series = sys.argv[1], sys.argv[2]
 O, P = 'gpurun_out/' + tag, 'profiles'
-for n in ('serl50', 'total512', 'serl10', 'serl10_pop128', 'pop64', 'pop128', 'pop341', 'mixed', 'mixed_nofused', 'mixed_total2048', 'rccl1'):
+for n in ('serl50', 'total512', 'serl10', 'serl10_samecu', 'serl10_pop128', 'pop64', 'pop128', 'pop341', 'mixed', 'mixed_nofused', 'mixed_total2048', 'rccl1'):
     line = [l for l in open('%s/bench_%s.json' % (O, n)) if l.startswith('{')][-1]
     open('%s/%s_bench_%s.json' % (P, series, n), 'w').write(line)
-for n in ('serl50', 'serl10_pop128', 'pop512'):
+for n in ('serl50', 'serl10', 'serl10_pop128', 'pop512'):
     shutil.copy('%s/kernel_stats_%s.md' % (O, n), '%s/%s_kernel_stats_%s.md' % (P, series, n))
 shutil.copy(O + '/valu_latency.json', '%s/%s_valu_latency.json' % (P, series))
 shutil.copy(O + '/valu_latency.json', P + '/valu_latency_current.json')      # bench.py: roofline_fp64.peak_measured

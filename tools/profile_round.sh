@@ -14,6 +14,7 @@ B="python $R/bench.py"
 timeout 900 $B --steps 10 --warmup 3 > $O/bench_serl50.json 2> $O/bench_serl50.err
 timeout 900 $B --total-pop 512 --steps 3 --warmup 1 > $O/bench_total512.json 2> $O/bench_total512.err                     # BASELINE config 4 on one GPU, parity vs the CPU restatement on all 1 536 episodes
 timeout 600 $B --workload serl10 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_serl10.json 2> $O/bench_serl10.err
+SERL_REMOTE_ACTOR=0 timeout 600 $B --workload serl10 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_serl10_samecu.json 2> $O/bench_serl10_samecu.err      # A/B: the streamed actor on the team's CU (round 5's kernel)
 timeout 600 $B --workload serl10 --pop 128 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_serl10_pop128.json 2> $O/bench_serl10_pop128.err   # 384 episodes, H = 72: two per team, two actor wavefronts
 timeout 600 $B --pop 64 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_pop64.json 2> $O/bench_pop64.err
 timeout 600 $B --pop 128 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_pop128.json 2> $O/bench_pop128.err     # 384 episodes: two per team
@@ -29,10 +30,12 @@ P1="$B --steps 1 --warmup 0 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o pf -- $P1 > $O/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o pw -- $P1 > $O/pmc_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES -d $O/pmc_sq -o ps -- $P1 > $O/pmc_sq.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_serl10 -o ${TAG}s10r -- $B --workload serl10 --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_serl10.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_serl10p128 -o ${TAG}s10 -- $B --workload serl10 --pop 128 --steps 2 --warmup 1 --no-cpu-baseline > $O/prof_serl10p128.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_pop512 -o ${TAG}p512 -- $B --pop 512 --steps 2 --warmup 1 --no-cpu-baseline > $O/prof_pop512.log 2>&1
 cd $R
 python tools/rocpd_summary.py $(ls $O/prof/*.db | head -1) "rocprofv3 --kernel-trace --stats -- $CMD" > $O/kernel_stats_serl50.md 2>> $O/err.txt
+python tools/rocpd_summary.py $(ls $O/prof_serl10/*.db | head -1) "rocprofv3 --kernel-trace --stats -- python bench.py --workload serl10 --steps 3 --warmup 1 --no-cpu-baseline" > $O/kernel_stats_serl10.md 2>> $O/err.txt
 python tools/rocpd_summary.py $(ls $O/prof_serl10p128/*.db | head -1) "rocprofv3 --kernel-trace --stats -- python bench.py --workload serl10 --pop 128 --steps 2 --warmup 1 --no-cpu-baseline" > $O/kernel_stats_serl10_pop128.md 2>> $O/err.txt
 python tools/rocpd_summary.py $(ls $O/prof_pop512/*.db | head -1) "rocprofv3 --kernel-trace --stats -- python bench.py --pop 512 --steps 2 --warmup 1 --no-cpu-baseline" > $O/kernel_stats_pop512.md 2>> $O/err.txt
 python tools/pmc_summary.py $O/pmc_fetch > $O/pmc_fetch.json 2>> $O/err.txt
@@ -43,5 +46,5 @@ SERL_PROFILE=1 timeout 300 python tools/ab.py 150 192 > $O/ab.txt 2>> $O/err.txt
 [ -f serl_amd/csrc/libserl_amd_prof2.so ] && SERL_PROFILE=1 SERL_LIB=$R/serl_amd/csrc/libserl_amd_prof2.so timeout 300 python tools/ab.py 150 > $O/ab_prof2.txt 2>> $O/err.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -ffp-contract=off tools/valu_latency.hip -o /tmp/valu_latency 2>> $O/err.txt && timeout 120 /tmp/valu_latency > $O/valu_latency.json 2>> $O/err.txt
 python tools/dag/critical_path.py nominal --latency $O/valu_latency.json > $O/critical_path.json 2>> $O/err.txt
-rm -rf $O/prof $O/prof_serl10p128 $O/prof_pop512 $O/pmc_fetch $O/pmc_write $O/pmc_sq     # (the databases are large; their summaries stay)
+rm -rf $O/prof $O/prof_serl10 $O/prof_serl10p128 $O/prof_pop512 $O/pmc_fetch $O/pmc_write $O/pmc_sq     # (the databases are large; their summaries stay)
 ls -la $O
