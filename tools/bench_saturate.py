@@ -24,6 +24,7 @@ ap.add_argument('--t-max', type=float, default=20.0)
 ap.add_argument('--members', type=int, default=2048)
 ap.add_argument('--modes', default='lane64,auto')
 ap.add_argument('--reps', type=int, default=2)
+ap.add_argument('--profile', action='store_true', help='with SERL_PROFILE=1 in the environment: cycles per env step wavefront 0 of workgroup 0 spent in the actor / dynamics / env bookkeeping (lane-per-episode kernels)')
 a = ap.parse_args()
 eng = serl_amd.RolloutEngine(0)
 spec = serl_amd.NetSpec(7, 3, 32, 3, 'tanh')
@@ -51,9 +52,16 @@ for E in [int(x) for x in a.episodes.split(',')]:
         info = eng.last_rollout_info()
         k_ms = min(ms)
         rate = steps / (k_ms * 1e-3)
+        extra = {}
+        if a.profile and os.environ.get('SERL_PROFILE'):
+            import ctypes
+            buf = (ctypes.c_ulonglong * 32)()
+            eng.lib.serl_debug_profile(eng.ctx, buf)
+            st = max(int(buf[3]), 1)
+            extra['cycles_per_env_step_wave0'] = dict(actor=int(buf[0] / st), dynamics=int(buf[1] / st), env=int(buf[2] / st), steps=int(buf[3]))
         chk = eng.rollout(w, spec, moe[:64], ref, t_max=a.t_max, kernel='team')
         same = bool(torch.equal(chk['fitness'], out['fitness'][:64]) and torch.equal(chk['length_steps'], out['length_steps'][:64]))
-        print(json.dumps(dict(what='saturating configuration (SURVEY 8d)', episodes=E, steps_per_episode=T, members=a.members, mode=mode, family=info['family'],
+        print(json.dumps(dict(extra, what='saturating configuration (SURVEY 8d)', episodes=E, steps_per_episode=T, members=a.members, mode=mode, family=info['family'],
                               workgroups=info['workgroups'], episodes_per_team_or_wave=info['episodes_per_team'], work_queue=info['work_queue'],
                               kernel_ms=[round(v, 2) for v in ms], env_steps=steps, env_steps_per_s=rate,
                               us_per_env_step_and_wavefront_or_team=k_ms * 1e3 / T,
