@@ -1087,6 +1087,134 @@ static __device__ __forceinline__ float serl_half_shfl(float v, int srclane)
   return __int_as_float(__builtin_amdgcn_ds_bpermute(srclane << 2, __float_as_int(v)));
 }
 
+// ---- one episode per LANE (rollout_variant.inc, round 6): the whole forward pass of the lane's own actor in the lane's registers ----------------------
+// The lane-per-episode kernels ran the wave-cooperative pass once per live lane -- 64 passes of ~9 k cycles per wavefront and env step, a quarter of a
+// step that already wastes no lane on the dynamics.  Here every lane walks ITS member's weights (global memory, L1 / L2: the rows of one member are
+// read by its num_evals lanes together) and keeps the two layers it needs in 64 registers.  Rows are computed eight at a time in a rolled loop and
+// shifted into place (static register indices, 3 KB of code per layer instead of 13), the arithmetic is the scalar statement of the ABI (oracle/rollout_ref.c
+// actor_forward: dot4, tree_sum): four interleaved fma partial sums over ascending j, bias + ((p0 + p1) + (p2 + p3)); LayerNorm sums as a balanced pairwise
+// tree per block of 16 rows, the blocks added in order.  H = 32, 7 observations, 3 actions (the SERL50 shape); other shapes keep the cooperative pass.
+static __device__ __forceinline__ bool serl_lane_actor_ok(const serl_rollout_desc &dd)
+{
+  return dd.hidden == 32 && dd.state_dim == 7 && dd.action_dim == 3;
+}
+static __device__ __forceinline__ float serl_tree16_regs(const float (&x)[32], const int o)
+{
+  const float a0 = x[o + 0] + x[o + 1], a1 = x[o + 2] + x[o + 3], a2 = x[o + 4] + x[o + 5], a3 = x[o + 6] + x[o + 7];
+  const float a4 = x[o + 8] + x[o + 9], a5 = x[o + 10] + x[o + 11], a6 = x[o + 12] + x[o + 13], a7 = x[o + 14] + x[o + 15];
+  const float b0 = a0 + a1, b1 = a2 + a3, b2 = a4 + a5, b3 = a6 + a7;
+  const float c0 = b0 + b1, c1 = b2 + b3;
+  return c0 + c1;
+}
+static __device__ __forceinline__ void serl_shift8(float (&h)[32], const float (&t)[8])
+{
+#pragma unroll
+  for (int i = 0; i < 24; ++i) h[i] = h[i + 8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[24 + i] = t[i];
+}
+static __device__ void serl_actor_forward_lane32(const serl_rollout_desc &dd, const float *w_lane, const float (&obs)[7], float (&act_out)[3])
+{
+  constexpr int H = 32;
+  const int L = __builtin_amdgcn_readfirstlane(dd.num_layers), act = __builtin_amdgcn_readfirstlane(dd.activation);
+  serl_gptr W = (serl_gptr)w_lane;                      // this lane's member
+  float h0[32], h1[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) { h0[i] = 0.0f; h1[i] = 0.0f; }
+  // ---- Linear(7, H) act
+  {
+    serl_gptr b0 = W + H * 7;
+#pragma nounroll
+    for (int c = 0; c < 4; ++c) {
+      float t[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        serl_gptr row = W + (8 * c + r) * 7;
+        float wv[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) wv[j] = row[j];
+        t[r] = serl_act(serl_dot7(b0[8 * c + r], wv, obs), act);
+      }
+      serl_shift8(h0, t);
+    }
+  }
+  const size_t lstride = (size_t)H * H + 3 * (size_t)H;
+  serl_gptr hid = W + (size_t)H * 7 + H;
+#pragma nounroll
+  for (int l = 0; l < L; ++l) {
+    serl_gptr Wl = hid + (size_t)l * lstride, bl = Wl + (size_t)H * H;
+    // four rows at a time in two register buffers: the NEXT four rows' weights are in flight while these are summed (one L2 round trip would otherwise stand
+    // in front of every chunk on a wavefront that has its SIMD to itself); the chunk loop is unrolled by two so that the buffers swap without copies
+    serl_v4f wa[4][8], wb[4][8];
+    float ba[4], bb[4];
+    auto fetch = [&](serl_v4f (&wv)[4][8], float (&bv)[4], const int c) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        serl_gptr4 row = (serl_gptr4)(Wl + (size_t)(4 * c + r) * H);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wv[r][q] = row[q];
+        bv[r] = bl[4 * c + r];
+      }
+    };
+    auto rows4 = [&](const serl_v4f (&wv)[4][8], const float (&bv)[4]) {
+      float t[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          p0 = __builtin_fmaf(wv[r][q].x, h0[4 * q], p0); p1 = __builtin_fmaf(wv[r][q].y, h0[4 * q + 1], p1);
+          p2 = __builtin_fmaf(wv[r][q].z, h0[4 * q + 2], p2); p3 = __builtin_fmaf(wv[r][q].w, h0[4 * q + 3], p3);
+        }
+        t[r] = bv[r] + ((p0 + p1) + (p2 + p3));
+      }
+#pragma unroll
+      for (int i = 0; i < 28; ++i) h1[i] = h1[i + 4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) h1[28 + i] = t[i];
+    };
+    fetch(wa, ba, 0);
+#pragma nounroll
+    for (int c = 0; c < 8; c += 2) {
+      fetch(wb, bb, c + 1);
+      rows4(wa, ba);
+      if (c + 2 < 8) fetch(wa, ba, c + 2);
+      rows4(wb, bb);
+    }
+    const float mean = (serl_tree16_regs(h1, 0) + serl_tree16_regs(h1, 16)) / (float)H;
+    float d2[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { const float dl = h1[i] - mean; d2[i] = dl * dl; }
+    const float var = serl_tree16_regs(d2, 0) + serl_tree16_regs(d2, 16);
+    const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
+#pragma nounroll
+    for (int c = 0; c < 4; ++c) {      // rows 8 c .. 8 c + 7 sit in h1[0 .. 7] (shifted as they are consumed); the new layer is shifted into h0
+      float t[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t[r] = serl_act(bl[H + 8 * c + r] * (h1[r] - mean) / den + bl[2 * H + 8 * c + r], act);
+      float z[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) z[r] = 0.0f;
+      serl_shift8(h1, z);
+      serl_shift8(h0, t);
+    }
+  }
+  // ---- Linear(H, 3) tanh
+  serl_gptr outl = hid + (size_t)L * lstride;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    serl_gptr4 row = (serl_gptr4)(outl + (size_t)i * H);
+    float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const serl_v4f wv = row[q];
+      p0 = __builtin_fmaf(wv.x, h0[4 * q], p0); p1 = __builtin_fmaf(wv.y, h0[4 * q + 1], p1);
+      p2 = __builtin_fmaf(wv.z, h0[4 * q + 2], p2); p3 = __builtin_fmaf(wv.w, h0[4 * q + 3], p3);
+    }
+    act_out[i] = det_tanhf((outl + (size_t)3 * H)[i] + ((p0 + p1) + (p2 + p3)));
+  }
+}
+
 // ---- two episodes per wavefront (rollout_half.inc, rollout_team_half.inc) -------------------------------------------------
 // Actor forward for H = 32, one episode per half-wavefront: lane gl of a half owns hidden row gl of ITS episode's member.
 // Same arithmetic as serl_actor_forward_small<32> (include/serl_amd.h): dot products as four interleaved fma partial sums
