@@ -54,6 +54,29 @@ CIT_HD int cit_lookup_index(CIT_TBL x, int n, double u)
 #endif
 CIT_NOINLINE int cit_lookup_index_slow(CIT_TBL x, int n, double u) { return cit_lookup_index(x, n, u); }
 
+// ... with a HINT (round 6, the lane-per-episode kernels): the interval an input fell into in the previous model evaluation.  An input almost never leaves its
+// interval between two evaluations (4 of 2 400 per episode), and idx == h holds exactly when (h == 0 or x[h] (<, <=) u) and (h == n - 2 or not x[h + 1] (<, <=) u)
+// -- two loads and two compares instead of 2 n of each; the interval is unique, so a verified hint IS the count's result.  If any lane of the wavefront fails
+// the test, the wavefront runs the count (which gives the other lanes what they had).
+#ifdef __HIPCC__
+CIT_HD int cit_lookup_index_h(CIT_TBL x, int n, double u, int32_t &hint)
+{
+  int h = hint;
+  h = h < 0 ? 0 : h;
+  h = h > n - 2 ? n - 2 : h;
+  const double xl = x[h], xh = x[h + 1];
+  const bool neg = u < 0.0;
+  const bool below = neg ? (xl <= u) : (xl < u);
+  const bool above = neg ? (xh <= u) : (xh < u);
+  const bool ok = ((h == 0) || below) && ((h == n - 2) || !above);
+  if (__builtin_expect(__ballot(!ok) != 0ULL, 0)) {
+    h = cit_lookup_index_slow(x, n, u);      // (out of line: 41 inlined counts would add 40 KB to an evaluation body that is at the instruction cache's size already)
+    hint = h;
+  }
+  return h;
+}
+#endif
+
 // index with a one-entry cache per breakpoint vector (cu/ci are locals of the model function): within one
 // model evaluation most of the 144 searches repeat an earlier (vector, input) pair (41 distinct, nominal)
 CIT_HD int cit_lookup_index_cached(CIT_TBL x, int n, double u, double *cu, int *ci)

@@ -21,6 +21,9 @@ static __device__ CIT_STEP_ATTR void CIT_STEP(CitCtx *gc, const double *cmd_in, 
   for (int i = 0; i < 29; ++i) lc.DW[i] = gc->DW[i];
   for (int i = 0; i < 4; ++i) lc.IW[i] = gc->IW[i];
   for (int i = 0; i < 12; ++i) lc.Y[i] = gc->Y[i];
+#ifdef CIT_USE_HINTS
+  for (int i = 0; i < CIT_USE_HINTS; ++i) lc.hint[i] = gc->hint[i];
+#endif
   for (int i = 0; i < 10; ++i) cmd[i] = cmd_in[i];
   lc.t = gc->t; lc.stop_time = gc->stop_time; lc.dt = gc->dt; lc.tick = gc->tick;
   lc.ro = gc->ro; lc.t3 = gc->t3; lc.err = gc->err; lc.bslot = gc->bslot;
@@ -55,6 +58,9 @@ static __device__ CIT_STEP_ATTR void CIT_STEP(CitCtx *gc, const double *cmd_in, 
   for (int i = 0; i < 29; ++i) gc->DW[i] = lc.DW[i];
   for (int i = 0; i < 4; ++i) gc->IW[i] = lc.IW[i];
   for (int i = 0; i < 12; ++i) { gc->Y[i] = lc.Y[i]; out_arg[i] = lc.Y[i]; }
+#ifdef CIT_USE_HINTS
+  for (int i = 0; i < CIT_USE_HINTS; ++i) gc->hint[i] = lc.hint[i];
+#endif
   gc->major = 1;
   gc->err = lc.err;
   gc->tick = lc.tick + 1;
@@ -64,3 +70,4 @@ static __device__ CIT_STEP_ATTR void CIT_STEP(CitCtx *gc, const double *cmd_in, 
 #undef CIT_MODEL
 #undef CIT_DERIV
 #undef CIT_STEP
+#undef CIT_USE_HINTS

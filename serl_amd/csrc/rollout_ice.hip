@@ -18,6 +18,7 @@ static_assert(cit_ice_RO_HI_W - cit_ice_RO_LO_W <= CIT_RO_LDS_WORDS, "LDS table 
 #define CIT_MODEL cit_ice_dag_model
 #define CIT_DERIV cit_ice_dag_derivatives
 #define CIT_STEP cit_step_ice
+#define CIT_USE_HINTS cit_ice_NSEARCH
 #include "citation_step_dev.h"
 #include "rollout_variant.inc"
 #undef CIT_NO_AXES

@@ -18,6 +18,7 @@ static_assert(cit_nominal_RO_HI_W - cit_nominal_RO_LO_W <= CIT_RO_LDS_WORDS, "LD
 #define CIT_MODEL cit_nominal_dag_model
 #define CIT_DERIV cit_nominal_dag_derivatives
 #define CIT_STEP cit_step_nominal
+#define CIT_USE_HINTS cit_nominal_NSEARCH      // (the index searches verify the previous evaluation's interval first: CitCtx.hint travels with the state)
 #include "citation_step_dev.h"
 #include "rollout_variant.inc"
 #undef CIT_NO_AXES

@@ -554,11 +554,12 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     c->timed = timed;
     return SERL_OK;
   }
-  // Round 6, the saturating regime: from ~160 episodes per CU on, one episode per LANE -- 64 per wavefront, the lane's own actor in its registers
-  // (rollout_device.h serl_actor_forward_lane32) -- outruns the queue launch of four-episode teams (65 536 episodes x 2 001 steps: 70 against 49 M env-steps/s;
-  // 32 768: 48 against 49; profiles/r06_saturate.jsonl).  The SERL50 actor shape, nominal / ice code, the attitude task, alone on the GPU.
+  // Round 6, the saturating regime: from ~96 episodes per CU on, one episode per LANE -- 64 per wavefront, the lane's own actor in its registers
+  // (rollout_device.h serl_actor_forward_lane32), at most two tables in flight and hinted index searches in the generated evaluation (tools/dag/codegen_lane.py) --
+  // outruns the queue launch of four-episode teams (episodes x 2 001 steps, M env-steps/s: 24 576: 55.7 against 49.2; 32 768: 72.6; 65 536: 141 against 49.6;
+  // 20 480: 46.9 against 49.0; profiles/r06_saturate.jsonl).  The SERL50 actor shape, nominal / ice code, the attitude task, alone on the GPU.
   if (lanes <= 0 && hint == SERL_KERNEL_AUTO && d->concurrent_episodes <= 0 && serl_has_lane_kernel(s.code) && d->hidden == 32 && d->state_dim == 7 &&
-      d->action_dim == 3 && d->n_episodes >= 160 * c->num_cus)
+      d->action_dim == 3 && d->n_episodes >= 96 * c->num_cus)
     lanes = 64;
   if (lanes <= 0 && serl_has_wave_kernel(s.code) && serl_use_team_rounds(c, d, hint, together)) {
     // more than 4 x CUs episodes, alone on the GPU: rounds of 4 x CUs episodes (four per team, every CU busy), then the rest
