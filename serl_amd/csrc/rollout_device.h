@@ -29,6 +29,8 @@ struct RolloutArgs {
   int32_t q0;                         // ... the first episode of the queue (episodes [q0, e_end) are taken as lane groups finish theirs)
   uint32_t jitter, jitter_sites;      // hand-over stress builds only (citation_wave.h, -DCITW_JITTER): seed of the pseudo-random pauses (0 = none), classes of sites that pause
   void *mail;                         // remote-actor team kernels (rollout_team.inc SERL_TEAM_REMOTE): device [episodes of the launch] SerlMail, zeroed per launch
+  const float *wt;                    // lane-per-episode kernels: the population's weights in groups of four parameters, member-minor: f32 [ceil(P / 4)][wt_members][4]
+  int32_t wt_members;                 // ... (serl_capi.hip serl_regroup_weights_kernel, once per launch); nullptr: every lane walks its member's row of d.weights
 };
 
 // The mailbox of ONE episode between its team workgroup and its actor workgroup on another CU (serl_rollout_teamr_kernel_<v>): the state x_k travels
@@ -243,7 +245,9 @@ struct SerlBarrierCreditPart {
 };
 
 #define SERL_MAX_HIDDEN 128
+#ifndef SERL_BLOCK
 #define SERL_BLOCK 256          // launch bound: up to 4 wavefronts (one per SIMD, 512 registers each) per workgroup share one LDS copy of the tables
+#endif
 
 // ---- actor MLP, wave-cooperative ----------------------------------------------------------------
 // One forward pass of ONE member's actor by all 64 lanes of a wavefront: lane r owns hidden rows r and
@@ -1212,6 +1216,130 @@ static __device__ void serl_actor_forward_lane32(const serl_rollout_desc &dd, co
       p2 = __builtin_fmaf(wv.z, h0[4 * q + 2], p2); p3 = __builtin_fmaf(wv.w, h0[4 * q + 3], p3);
     }
     act_out[i] = det_tanhf((outl + (size_t)3 * H)[i] + ((p0 + p1) + (p2 + p3)));
+  }
+}
+
+// The same forward pass over the REGROUPED weights (RolloutArgs.wt: [ceil(P / 4)][members][4], serl_capi.hip serl_regroup_weights_kernel).  A lane that walks
+// its member's row of [members][P] asks the texture path for 64 different cache lines per load instruction (a row of 32 weights is one line: four rows in
+// flight x 64 lanes are the whole 32 KB L1), and the forward pass -- 3.7 k fma per lane -- cost 0.23 M cycles per wavefront and env step.  Here parameter
+// group g of the members of 64 consecutive episodes is one run of 1 KB when the episodes' members are consecutive (evaluate_pop: member = episode / num_evals
+// or episode mod members), every load instruction a wave-uniform base (group g) + the lane's member x 16 B.  Every parameter offset of the packed layout is
+// a multiple of four for H = 32 (224, 256, 1120 per hidden layer), so a group never straddles two tensors.  Same arithmetic, same order: bit-identical.
+static __device__ void serl_actor_forward_lane32_t(const serl_rollout_desc &dd, const float *wt, const int wt_members, const unsigned member, const float (&obs)[7],
+                                                   float (&act_out)[3])
+{
+  constexpr int H = 32;
+  const int L = __builtin_amdgcn_readfirstlane(dd.num_layers), act = __builtin_amdgcn_readfirstlane(dd.activation);
+  typedef const __attribute__((address_space(1))) char *gbytes;
+  const gbytes base = (gbytes)wt;
+  const unsigned gs = (unsigned)__builtin_amdgcn_readfirstlane(wt_members) * 16u;      // bytes from group g to group g + 1 (wave-uniform)
+  const unsigned moff = member * 16u;
+  // a load = wave-uniform 64-bit address of the group (SGPR pair: global_load_dwordx4 v, v_off, s[..]) + the lane's 32-bit offset member x 16 (serl_capi.hip regroups at most 2^22 members)
+  auto at = [&](const int g0) -> gbytes { return base + (size_t)g0 * (size_t)gs; };
+  auto ld4 = [&](const gbytes gp, const int k) -> serl_v4f { const gbytes q = gp + (size_t)((unsigned)k * gs); return *(serl_gptr4)(q + moff); };
+  float h0[32], h1[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) { h0[i] = 0.0f; h1[i] = 0.0f; }
+  // ---- Linear(7, H) act: eight rows = 56 weights = 14 groups at a time
+  {
+#pragma nounroll
+    for (int c = 0; c < 4; ++c) {
+      float wf[56], bf[8];
+      const gbytes gw = at(14 * c), gb = at(56 + 2 * c);
+#pragma unroll
+      for (int g = 0; g < 14; ++g) { const serl_v4f v = ld4(gw, g); wf[4 * g] = v.x; wf[4 * g + 1] = v.y; wf[4 * g + 2] = v.z; wf[4 * g + 3] = v.w; }
+#pragma unroll
+      for (int g = 0; g < 2; ++g) { const serl_v4f v = ld4(gb, g); bf[4 * g] = v.x; bf[4 * g + 1] = v.y; bf[4 * g + 2] = v.z; bf[4 * g + 3] = v.w; }
+      float t[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        float wv[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) wv[j] = wf[7 * r + j];
+        t[r] = serl_act(serl_dot7(bf[r], wv, obs), act);
+      }
+      serl_shift8(h0, t);
+    }
+  }
+  constexpr int lgroups = (H * H + 3 * H) / 4, hid = (H * 7 + H) / 4;      // groups per hidden layer, first group of the first hidden layer
+#pragma nounroll
+  for (int l = 0; l < L; ++l) {
+    const int Wl = hid + l * lgroups, bl = Wl + H * H / 4;       // groups: weights (row r = groups 8 r .. 8 r + 7), then bias / gamma / beta (8 groups each)
+    serl_v4f wa[4][8], wb[4][8], ba, bb;
+    auto fetch = [&](serl_v4f (&wv)[4][8], serl_v4f &bv, const int c) {
+      const gbytes gp = at(Wl + 32 * c);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wv[r][q] = ld4(gp, r * 8 + q);
+      bv = ld4(at(bl + c), 0);
+    };
+    auto rows4 = [&](const serl_v4f (&wv)[4][8], const serl_v4f &bv) {
+      const float bvs[4] = {bv.x, bv.y, bv.z, bv.w};
+      float t[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          p0 = __builtin_fmaf(wv[r][q].x, h0[4 * q], p0); p1 = __builtin_fmaf(wv[r][q].y, h0[4 * q + 1], p1);
+          p2 = __builtin_fmaf(wv[r][q].z, h0[4 * q + 2], p2); p3 = __builtin_fmaf(wv[r][q].w, h0[4 * q + 3], p3);
+        }
+        t[r] = bvs[r] + ((p0 + p1) + (p2 + p3));
+      }
+#pragma unroll
+      for (int i = 0; i < 28; ++i) h1[i] = h1[i + 4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) h1[28 + i] = t[i];
+    };
+    fetch(wa, ba, 0);
+#pragma nounroll
+    for (int c = 0; c < 8; c += 2) {
+      fetch(wb, bb, c + 1);
+      rows4(wa, ba);
+      if (c + 2 < 8) fetch(wa, ba, c + 2);
+      rows4(wb, bb);
+    }
+    const float mean = (serl_tree16_regs(h1, 0) + serl_tree16_regs(h1, 16)) / (float)H;
+    float d2[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { const float dl = h1[i] - mean; d2[i] = dl * dl; }
+    const float var = serl_tree16_regs(d2, 0) + serl_tree16_regs(d2, 16);
+    const float den = sqrtf(var / (float)(H - 1)) + 1e-6f;
+#pragma nounroll
+    for (int c = 0; c < 4; ++c) {      // rows 8 c .. 8 c + 7 sit in h1[0 .. 7] (shifted as they are consumed); the new layer is shifted into h0
+      float gm[8], bt[8];
+      const gbytes gg = at(bl + 8 + 2 * c);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const serl_v4f v = ld4(gg, g), u = ld4(gg, 8 + g);
+        gm[4 * g] = v.x; gm[4 * g + 1] = v.y; gm[4 * g + 2] = v.z; gm[4 * g + 3] = v.w;
+        bt[4 * g] = u.x; bt[4 * g + 1] = u.y; bt[4 * g + 2] = u.z; bt[4 * g + 3] = u.w;
+      }
+      float t[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t[r] = serl_act(gm[r] * (h1[r] - mean) / den + bt[r], act);
+      float z[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) z[r] = 0.0f;
+      serl_shift8(h1, z);
+      serl_shift8(h0, t);
+    }
+  }
+  // ---- Linear(H, 3) tanh
+  const gbytes go = at(hid + L * lgroups);
+  const serl_v4f ob = ld4(go, 3 * H / 4);
+  const float obs3[3] = {ob.x, ob.y, ob.z};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const serl_v4f wv = ld4(go, i * 8 + q);
+      p0 = __builtin_fmaf(wv.x, h0[4 * q], p0); p1 = __builtin_fmaf(wv.y, h0[4 * q + 1], p1);
+      p2 = __builtin_fmaf(wv.z, h0[4 * q + 2], p2); p3 = __builtin_fmaf(wv.w, h0[4 * q + 3], p3);
+    }
+    act_out[i] = det_tanhf(obs3[i] + ((p0 + p1) + (p2 + p3)));
   }
 }
 

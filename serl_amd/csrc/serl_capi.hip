@@ -211,6 +211,43 @@ static void serl_launch_dyn_team(int code, const RolloutArgs &a, const double *c
 static bool serl_has_wave_kernel(int code) { return code >= SERL_DYN_NOMINAL && code <= SERL_DYN_TEST; }
 static bool serl_has_lane_kernel(int code) { return code == SERL_DYN_NOMINAL || code == SERL_DYN_ICE; }
 
+// Lane-per-episode kernels (rollout_device.h serl_actor_forward_lane32_t): the population [members][stride] regrouped to [ceil(P / 4)][mpad][4], so that parameter
+// group g of 64 consecutive members is ONE run of 1 KB.  Reads run along a member's row, writes are 16 B pieces (30 MB for 2 048 SERL50 actors: microseconds in front of a
+// launch of hundreds of milliseconds).
+__global__ void serl_regroup_weights_kernel(const float *w, int64_t stride, int32_t n_members, int32_t P, float *out, int32_t mpad)
+{
+  const int g = blockIdx.y * blockDim.x + threadIdx.x, m = blockIdx.x;
+  if (4 * g >= P) return;
+  const float *row = w + (size_t)m * stride + 4 * (size_t)g;
+  float4 v;
+  v.x = row[0];
+  v.y = 4 * g + 1 < P ? row[1] : 0.0f;
+  v.z = 4 * g + 2 < P ? row[2] : 0.0f;
+  v.w = 4 * g + 3 < P ? row[3] : 0.0f;
+  *(float4 *)(out + ((size_t)g * mpad + m) * 4) = v;
+}
+
+static int serl_regroup_weights(serl_ctx *c, const serl_rollout_desc *d, RolloutArgs &a, hipStream_t stream)
+{
+  const int P = d->hidden * d->state_dim + d->hidden + d->num_layers * (d->hidden * d->hidden + 3 * d->hidden) + d->action_dim * d->hidden + d->action_dim;
+  const int groups = (P + 3) / 4, mpad = (d->n_members + 63) / 64 * 64;
+  const size_t bytes = (size_t)groups * mpad * 16;
+  const int slot = c->wt_next;
+  c->wt_next = (c->wt_next + 1) % SERL_WT_SLOTS;
+  if (c->wt_cap[slot] < bytes) {
+    if (c->wt[slot]) HIP_TRY(hipFree(c->wt[slot]));      // (waits for the launches that read it)
+    c->wt[slot] = nullptr; c->wt_cap[slot] = 0;
+    HIP_TRY(hipMalloc(&c->wt[slot], bytes));
+    c->wt_cap[slot] = bytes;
+  }
+  hipLaunchKernelGGL(serl_regroup_weights_kernel, dim3(d->n_members, (groups + 255) / 256), dim3(256), 0, stream, d->weights, d->weight_stride, d->n_members, P,
+                     (float *)c->wt[slot], mpad);
+  HIP_TRY(hipGetLastError());
+  a.wt = (const float *)c->wt[slot];
+  a.wt_members = mpad;
+  return SERL_OK;
+}
+
 static void serl_launch_rollout_wave(int code, const RolloutArgs &a, int grid, hipStream_t stream)
 {
   switch (code) {
@@ -348,6 +385,7 @@ int serl_ctx_create(int device, serl_ctx **out)
     c->env_profile = getenv("SERL_PROFILE") != nullptr;
     c->env_split_actor = (e = getenv("SERL_SPLIT_ACTOR")) ? atoi(e) : 0;
     c->env_remote_actor = (e = getenv("SERL_REMOTE_ACTOR")) ? atoi(e) : 1;
+    c->env_lane_regroup = ((e = getenv("SERL_LANE_WEIGHTS")) && !strcmp(e, "rows")) ? 0 : 1;
     c->env_mixed_place = (e = getenv("SERL_MIXED_PLACE")) ? atoi(e) : SERL_MIXED_PLACE_DEFAULT;
     c->env_jitter = (e = getenv("SERL_JITTER_SEED")) ? (unsigned)strtoul(e, nullptr, 0) : 0u;
     c->env_jitter_sites = (e = getenv("SERL_JITTER_SITES")) ? (unsigned)strtoul(e, nullptr, 0) : ~0u;
@@ -365,6 +403,7 @@ int serl_ctx_destroy(serl_ctx *c)
   (void)hipSetDevice(c->device);
   for (auto &s : c->slots) if (s.blob) (void)hipFree(s.blob);
   if (c->mail) (void)hipFree(c->mail);
+  for (int i = 0; i < SERL_WT_SLOTS; ++i) if (c->wt[i]) (void)hipFree(c->wt[i]);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->prof) (void)hipFree(c->prof);
@@ -554,12 +593,12 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     c->timed = timed;
     return SERL_OK;
   }
-  // Round 6, the saturating regime: from ~96 episodes per CU on, one episode per LANE -- 64 per wavefront, the lane's own actor in its registers
-  // (rollout_device.h serl_actor_forward_lane32), at most two tables in flight and hinted index searches in the generated evaluation (tools/dag/codegen_lane.py) --
-  // outruns the queue launch of four-episode teams (episodes x 2 001 steps, M env-steps/s: 24 576: 55.7 against 49.2; 32 768: 72.6; 65 536: 141 against 49.6;
-  // 20 480: 46.9 against 49.0; profiles/r06_saturate.jsonl).  The SERL50 actor shape, nominal / ice code, the attitude task, alone on the GPU.
+  // Round 6, the saturating regime: from 80 episodes per CU on, one episode per LANE -- 64 per wavefront, the lane's own actor in its registers over
+  // the regrouped weights (rollout_device.h serl_actor_forward_lane32_t), at most two tables in flight and hinted index searches in the generated evaluation
+  // (tools/dag/codegen_lane.py) -- outruns the queue launch of four-episode teams (episodes x 2 001 steps, M env-steps/s: 16 384: 47.4 against 49.1; 20 480: 53.0
+  // against 49.0; 32 768: 82.8; 65 536: 165.6 against 49.6; profiles/r06_saturate.jsonl).  The SERL50 actor shape, nominal / ice code, the attitude task, alone on the GPU.
   if (lanes <= 0 && hint == SERL_KERNEL_AUTO && d->concurrent_episodes <= 0 && serl_has_lane_kernel(s.code) && d->hidden == 32 && d->state_dim == 7 &&
-      d->action_dim == 3 && d->n_episodes >= 96 * c->num_cus)
+      d->action_dim == 3 && d->n_episodes >= 80 * c->num_cus)
     lanes = 64;
   if (lanes <= 0 && serl_has_wave_kernel(s.code) && serl_use_team_rounds(c, d, hint, together)) {
     // more than 4 x CUs episodes, alone on the GPU: rounds of 4 x CUs episodes (four per team, every CU busy), then the rest
@@ -642,6 +681,10 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   const int wpb = serl_waves_per_block(c, waves);
   a.block = 64 * wpb;
   const int grid = (waves + wpb - 1) / wpb;
+  if (c->env_lane_regroup && d->hidden == 32 && d->state_dim == 7 && d->action_dim == 3 && d->n_members <= (1 << 22)) {      // (rollout_device.h serl_lane_actor_ok)
+    const int rc = serl_regroup_weights(c, d, a, stream);
+    if (rc != SERL_OK) return rc;
+  }
   if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
   if (s.code == SERL_DYN_NOMINAL) serl_launch_rollout_nominal(a, grid, stream);
   else serl_launch_rollout_ice(a, grid, stream);

@@ -8,6 +8,7 @@
 #define SERL_MAX_SLOTS 16
 #define SERL_QUEUE_COUNTERS 64
 #define SERL_MIXED_PLACE_DEFAULT 2
+#define SERL_WT_SLOTS 4                  // regrouped weight copies of lane-per-episode launches in flight (a ring)
 #define SERL_MAIL_REGIONS 8              // mailbox regions of remote-actor launches in flight (a ring, like the queue counters)
 #define SERL_MIXED_STATES 8             // placement states of serl_rollout_multi launches in flight (a ring, like the queue counters)
 
@@ -51,5 +52,9 @@ struct serl_ctx {
   int env_remote_actor = 1;             // SERL_REMOTE_ACTOR=0: streamed actors of one-episode teams stay on the team's CU (rollout_team_<v>.hip serl_rollout_teams_kernel_; A/B)
   void *mail = nullptr;                 // device [SERL_MAIL_REGIONS][num_cus] SerlMail: team <-> remote actor workgroup (rollout_teamr_<v>.hip)
   int mail_next = 0;
+  int env_lane_regroup = 1;             // SERL_LANE_WEIGHTS=rows: the lane-per-episode kernels walk [members][P] rows instead of the regrouped copy (A/B)
+  void *wt[SERL_WT_SLOTS] = {};         // lane-per-episode kernels: regrouped weights [ceil(P / 4)][members up to 64][4] of the launches in flight (a ring; grown on demand)
+  size_t wt_cap[SERL_WT_SLOTS] = {};
+  int wt_next = 0;
   int32_t last_info[8] = {};            // serl_last_rollout_info: what the most recent rollout call launched (family, workgroups, episodes per team, queue, actor wavefronts, streamed, launches, code)
 };
