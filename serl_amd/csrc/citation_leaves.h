@@ -110,6 +110,28 @@ CIT_HD double cit_lookup2d_at(CIT_TBL xr, int nr, CIT_TBL xc, CIT_TBL z, int ix,
   return r + a;
 }
 
+// ... with the x-direction quotients precomputed per table and interval (round 6, the lane-per-episode kernels: g_sl, staged beside the tables by
+// rollout_variant.inc with the operations above -- s[ix + (nr - 1) iy] = (z[ix + 1][iy] - z[ix][iy]) / (xr[ix + 1] - xr[ix]), 1-D: s[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i])):
+// the same values enter the same multiply-adds, the interpolation keeps the one division whose dividend depends on the inputs
+CIT_HD double cit_lookup1d_at_s(CIT_TBL x, int i, double u, CIT_TBL y, CIT_TBL s)
+{
+  double r = s[i];
+  r = r * (u - x[i]);
+  return r + y[i];
+}
+
+CIT_HD double cit_lookup2d_at_s(CIT_TBL xr, int nr, CIT_TBL xc, CIT_TBL z, CIT_TBL s, int ix, int iy, double u0, double u1)
+{
+  const double wx = u0 - xr[ix];
+  const double z00 = z[ix + nr * iy], z01 = z[ix + nr * (iy + 1)];
+  double a = s[ix + (nr - 1) * iy]; a = a * wx; a = a + z00;
+  double b = s[ix + (nr - 1) * (iy + 1)]; b = b * wx; b = b + z01;
+  const double y0 = xc[iy];
+  const double dy = xc[iy + 1] - y0;
+  double r = b - a; r = r / dy; r = r * (u1 - y0);
+  return r + a;
+}
+
 CIT_HD double cit_lookup1d(CIT_TBL x, int n, double u, CIT_TBL y)
 {
   const int i = cit_lookup_index(x, n, u);

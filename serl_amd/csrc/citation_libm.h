@@ -61,12 +61,26 @@ CITW_LIBM_FN double citw_libm_hi_xor(double v, unsigned bits)
   return t.d;
 }
 
+// The general-purpose bodies behind the range guards below, OUT OF LINE on the device when CITW_LIBM_COLD_CALLS is set (the lane-group team kernels: 1.2 KB of
+// ocml sincos at each of four call sites, 1.7 KB of pow, in the middle of a loop that has to live in a 64 KB instruction cache shared by two CUs; a guard
+// that fails -- never on flight angles -- pays a call)
+#if defined(__HIPCC__) && defined(CITW_LIBM_COLD_CALLS) && defined(__HIP_DEVICE_COMPILE__)
+static __device__ __attribute__((noinline, cold)) void citw_general_sincos(const double x, double *s, double *c) { sincos(x, s, c); }
+static __device__ __attribute__((noinline, cold)) double citw_general_pow(const double x, const double c) { return pow(x, c); }
+static __device__ __attribute__((noinline, cold)) double citw_general_exp(const double x) { return exp(x); }
+static __device__ __attribute__((noinline, cold)) double citw_general_log10(const double x) { return log10(x); }
+static __device__ __attribute__((noinline, cold)) double citw_general_log(const double x) { return log(x); }
+#else
+#define citw_general_sincos sincos
+#define citw_general_pow pow
+#endif
+
 // sin and cos of x
 CITW_LIBM_FN void citw_sincos(const double x, double *s, double *c CITW_LIBM_KPARAMS)
 {
 #ifndef CITW_LIBM_NO_FALLBACK               // (tools/isa/role_isa.py counts the instructions of the short bodies without the cold paths)
-  if (!(__builtin_fabs(x) < 1.0e5)) {      // huge, inf, NaN: the general-purpose body (beyond 1e5 the two-part pi/2 loses accuracy gradually)
-    sincos(x, s, c);
+  if (__builtin_expect(!(__builtin_fabs(x) < 1.0e5), 0)) {      // huge, inf, NaN: the general-purpose body (beyond 1e5 the two-part pi/2 loses accuracy gradually)
+    citw_general_sincos(x, s, c);
     return;
   }
 #endif
@@ -118,7 +132,7 @@ CITW_LIBM_FN double citw_tan(const double x CITW_LIBM_KPARAMS)
 CITW_LIBM_FN double citw_pow(const double x, const double c CITW_LIBM_KPARAMS)
 {
 #ifndef CITW_LIBM_NO_FALLBACK
-  if (!(x >= 0.71 && x <= 1.41 && __builtin_fabs(c) <= 16.0)) return pow(x, c);
+  if (__builtin_expect(!(x >= 0.71 && x <= 1.41 && __builtin_fabs(c) <= 16.0), 0)) return citw_general_pow(x, c);      // (expected cold: block placement moves the general body behind the loop)
 #endif
   const double LN2_HI = CITW_LK(0, 0x1.62e42fefa39efp-1), LN2_LO = CITW_LK(1, 0x1.abc9e3b39803fp-56), INV_LN2 = CITW_LK(2, 0x1.71547652b82fep+0);
   // ln x = 2 q + q z (2/3 + z (2/5 + ... )), q = f / (2 + f), f = x - 1 (exact for x in [1/2, 2])

@@ -15,9 +15,12 @@ namespace bdag {
 #define CIT_NO_AXES 1
 #include "gen/citation_ice_lane.inc"
 static_assert(cit_ice_RO_HI_W - cit_ice_RO_LO_W <= CIT_RO_LDS_WORDS, "LDS table window too small");
+static_assert(8 * (CIT_RO_LDS_WORDS + cit_ice_NSLOPE) <= 160 * 1024, "tables + interval quotients beyond the 160 KB of LDS");
 #define CIT_MODEL cit_ice_dag_model
 #define CIT_DERIV cit_ice_dag_derivatives
 #define CIT_STEP cit_step_ice
+#define CIT_SLOPE_DESC cit_ice_slope_desc      // (precomputed x-direction quotients of the tables: rollout_variant.inc stages them, citation_leaves.h cit_lookup2d_at_s)
+#define CIT_SLOPE_TABLES cit_ice_NSLOPE_TABLES
 #define CIT_USE_HINTS cit_ice_NSEARCH
 #include "citation_step_dev.h"
 #include "rollout_variant.inc"

@@ -15,9 +15,12 @@ namespace bdag {
 #define CIT_NO_AXES 1
 #include "gen/citation_nominal_lane.inc"
 static_assert(cit_nominal_RO_HI_W - cit_nominal_RO_LO_W <= CIT_RO_LDS_WORDS, "LDS table window too small");
+static_assert(8 * (CIT_RO_LDS_WORDS + cit_nominal_NSLOPE) <= 160 * 1024, "tables + interval quotients beyond the 160 KB of LDS");
 #define CIT_MODEL cit_nominal_dag_model
 #define CIT_DERIV cit_nominal_dag_derivatives
 #define CIT_STEP cit_step_nominal
+#define CIT_SLOPE_DESC cit_nominal_slope_desc      // (precomputed x-direction quotients of the tables: rollout_variant.inc stages them, citation_leaves.h cit_lookup2d_at_s)
+#define CIT_SLOPE_TABLES cit_nominal_NSLOPE_TABLES
 #define CIT_USE_HINTS cit_nominal_NSEARCH      // (the index searches verify the previous evaluation's interval first: CitCtx.hint travels with the state)
 #include "citation_step_dev.h"
 #include "rollout_variant.inc"

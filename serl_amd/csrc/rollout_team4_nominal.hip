@@ -13,7 +13,13 @@
 #ifndef CITW_TEAM_INC
 #define CITW_TEAM_INC "gen/citation_nominal_teamg.inc"      // (tools/exp_build.py: A/B builds around another generated file)
 #endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(CITW_LIBM_COLD_CALLS)      // (A/B builds: measured slower, profiles/r06_experiments.md section 5)
+#define exp citw_general_exp            // (the generated model calls ocml's exp / log10 behind gates that are closed at the trimmed flight condition)
+#define log10 citw_general_log10
+#endif
 #include CITW_TEAM_INC
+#undef exp
+#undef log10
 #define VARIANT nominal
 #include "rollout_team.inc"
 #undef VARIANT

@@ -211,3 +211,28 @@ def test_every_cross_wavefront_read_of_the_generated_team_code_is_covered_by_its
                 sl = int(r.group(1))
                 q, k = y_pub[sl]
                 assert q == b or pwaited.get(q, 0) >= k, 'wave %d reads g_y[%d] behind B1 without the producer\'s flag (%d, %d)' % (b, sl, q, k)
+
+
+def test_interpolation_over_precomputed_quotients_equals_the_reference_order(tmp_path):
+    """Round 6 (lane-per-episode kernels): citation_leaves.h cit_lookup2d_at_s / cit_lookup1d_at_s read the x-direction quotient of a table interval from g_sl, where
+    rollout_variant.inc left it when it staged the tables -- (z[ix + 1] - z[ix]) / (x[ix + 1] - x[ix]), the interpolation's own first two operations (rt_Lookup2D_Normal
+    of the reference's library).  On the host, random tables and inputs (inside, outside, on both sides of zero): bit for bit against cit_lookup2d_at /
+    cit_lookup1d_at; and the generated files' plan fits the LDS next to the tables."""
+    import subprocess, re
+    exe = str(tmp_path / 'lsh')
+    subprocess.run(['g++', '-O2', '-ffp-contract=off', '-D_GNU_SOURCE', '-I', os.path.join(ROOT, 'serl_amd', 'csrc'),
+                    os.path.join(ROOT, 'tests', 'tools', 'leaves_slopes_host.cpp'), '-o', exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    bad, n = (int(x) for x in r.stdout.split())
+    assert r.returncode == 0 and bad == 0 and n == 200000, r.stdout
+    for v in ('nominal', 'ice'):
+        text = open(os.path.join(ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_lane.inc' % v)).read()
+        words, tables = (int(x) for x in re.search(r'cit_%s_NSLOPE = (\d+), cit_%s_NSLOPE_TABLES = (\d+)' % (v, v), text).groups())
+        rows = re.findall(r'^  \{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},$', text, re.M)
+        assert len(rows) == tables and tables >= 60
+        end = 0
+        for kind, zw, nr, nc, xw, off in (tuple(int(x) for x in row) for row in rows):      # the windows of g_sl follow each other without gaps or overlaps
+            assert off == end and kind in (1, 2)
+            end += (nr - 1) * (nc if kind == 2 else 1)
+        assert end == words and 8 * (12040 + words) <= 160 * 1024
+        assert text.count('cit_lookup2d_at_s(') + text.count('cit_lookup1d_at_s(') >= 70
