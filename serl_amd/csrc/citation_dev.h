@@ -43,7 +43,8 @@ struct CitCtx {
   CitAxes ax;            // trigonometry + rotation matrices of the current model evaluation
   int32_t bslot;         // first word of this episode's window in g_B (LDS flavour)
   int32_t err;           // CIT_ERR_* flags
-  int32_t hint[48];      // (lane-per-episode DAG kernels) interval every index search found in the previous model evaluation (citation_leaves.h cit_lookup_index_h)
+  double *dwm;           // (lane-per-episode DAG kernels) the Derivative-block banks of the CALLER's context: the evaluation reads / writes them there (citation_step_dev.h CIT_DW_IN_MEMORY)
+  uint32_t hint[8];      // (lane-per-episode DAG kernels) interval every index search found in the previous model evaluation, five bits each, six to a word (citation_leaves.h cit_lookup_index_h)
 };
 
 // inlining policy: the model body, derivatives and the S-function bodies are inlined into the step
@@ -189,7 +190,7 @@ static __device__ inline void cit_reset(CitCtx *c, const double *ro, const doubl
   c->IW[0] = iw[0]; c->IW[1] = iw[1]; c->IW[2] = iw[2]; c->IW[3] = 0;
   for (int i = 0; i < 12; ++i) c->Y[i] = 0.0;
   c->ro = ro; c->t3 = t3; c->dt = dt; c->major = 1; c->tick = 0; c->t = 0.0; c->stop_time = 0.0; c->err = 0;
-  for (int i = 0; i < 48; ++i) c->hint[i] = 0;
+  for (int i = 0; i < 8; ++i) c->hint[i] = 0u;
 }
 
 // Dormand-Prince "ode5" tableau as the reference's literal pool holds it (0x13688, 0x13898..0x13938)

@@ -59,10 +59,12 @@ CIT_NOINLINE int cit_lookup_index_slow(CIT_TBL x, int n, double u) { return cit_
 // -- two loads and two compares instead of 2 n of each; the interval is unique, so a verified hint IS the count's result.  If any lane of the wavefront fails
 // the test, the wavefront runs the count (which gives the other lanes what they had).
 #ifdef __HIPCC__
-CIT_HD int cit_lookup_index_h(CIT_TBL x, int n, double u, int32_t &hint)
+// The hints are PACKED, five bits each (an interval index is below 31: the longest breakpoint vector has 22 entries), six to a word: 46 hints of an evaluation live
+// in 8 registers instead of 46 across the whole straight-line evaluation (every register the evaluation body does not hold is a spill less: a reload costs the
+// lane-per-episode kernels ~200 cycles, there is one wavefront per SIMD).
+CIT_HD int cit_lookup_index_h(CIT_TBL x, int n, double u, uint32_t &word, const int shift)
 {
-  int h = hint;
-  h = h < 0 ? 0 : h;
+  int h = (int)((word >> shift) & 31u);
   h = h > n - 2 ? n - 2 : h;
   const double xl = x[h], xh = x[h + 1];
   const bool neg = u < 0.0;
@@ -71,7 +73,7 @@ CIT_HD int cit_lookup_index_h(CIT_TBL x, int n, double u, int32_t &hint)
   const bool ok = ((h == 0) || below) && ((h == n - 2) || !above);
   if (__builtin_expect(__ballot(!ok) != 0ULL, 0)) {
     h = cit_lookup_index_slow(x, n, u);      // (out of line: 41 inlined counts would add 40 KB to an evaluation body that is at the instruction cache's size already)
-    hint = h;
+    word = (word & ~(31u << shift)) | ((uint32_t)h << shift);
   }
   return h;
 }

@@ -18,11 +18,17 @@ static __device__ CIT_STEP_ATTR void CIT_STEP(CitCtx *gc, const double *cmd_in, 
   CitCtx lc;
   double y[19], f[6][19], cmd[10], out[12];
   for (int i = 0; i < 19; ++i) { lc.X[i] = gc->X[i]; y[i] = lc.X[i]; }
+#ifdef CIT_DW_IN_MEMORY      // (the DAG evaluation reads the banks where it needs them and writes them in the major step: gen/citation_<v>_lane.inc)
+  lc.dwm = gc->DW;
+#else
   for (int i = 0; i < 29; ++i) lc.DW[i] = gc->DW[i];
+#endif
   for (int i = 0; i < 4; ++i) lc.IW[i] = gc->IW[i];
+#ifndef CIT_Y_IS_STATE      // (the DAG evaluation latches rtY = the first twelve states of the major step, which y[] holds anyway: twenty-four registers less across six evaluations)
   for (int i = 0; i < 12; ++i) lc.Y[i] = gc->Y[i];
+#endif
 #ifdef CIT_USE_HINTS
-  for (int i = 0; i < CIT_USE_HINTS; ++i) lc.hint[i] = gc->hint[i];
+  for (int i = 0; i < (CIT_USE_HINTS + 5) / 6; ++i) lc.hint[i] = gc->hint[i];
 #endif
   for (int i = 0; i < 10; ++i) cmd[i] = cmd_in[i];
   lc.t = gc->t; lc.stop_time = gc->stop_time; lc.dt = gc->dt; lc.tick = gc->tick;
@@ -55,11 +61,17 @@ static __device__ CIT_STEP_ATTR void CIT_STEP(CitCtx *gc, const double *cmd_in, 
       gc->X[i] = acc + y[i];
     }
   }
+#ifndef CIT_DW_IN_MEMORY
   for (int i = 0; i < 29; ++i) gc->DW[i] = lc.DW[i];
+#endif
   for (int i = 0; i < 4; ++i) gc->IW[i] = lc.IW[i];
+#ifdef CIT_Y_IS_STATE
+  for (int i = 0; i < 12; ++i) { gc->Y[i] = y[i]; out_arg[i] = y[i]; }
+#else
   for (int i = 0; i < 12; ++i) { gc->Y[i] = lc.Y[i]; out_arg[i] = lc.Y[i]; }
+#endif
 #ifdef CIT_USE_HINTS
-  for (int i = 0; i < CIT_USE_HINTS; ++i) gc->hint[i] = lc.hint[i];
+  for (int i = 0; i < (CIT_USE_HINTS + 5) / 6; ++i) gc->hint[i] = lc.hint[i];
 #endif
   gc->major = 1;
   gc->err = lc.err;
@@ -71,3 +83,5 @@ static __device__ CIT_STEP_ATTR void CIT_STEP(CitCtx *gc, const double *cmd_in, 
 #undef CIT_DERIV
 #undef CIT_STEP
 #undef CIT_USE_HINTS
+#undef CIT_Y_IS_STATE
+#undef CIT_DW_IN_MEMORY

@@ -13,6 +13,7 @@ namespace bdag {
 #define CIT_B_AT(i) (c->B[(i)])
 #define SERL_FLAVOUR_LDS 0
 #define CIT_NO_AXES 1
+#define CIT_DWM_PTR double *
 #include "gen/citation_ice_lane.inc"
 static_assert(cit_ice_RO_HI_W - cit_ice_RO_LO_W <= CIT_RO_LDS_WORDS, "LDS table window too small");
 static_assert(8 * (CIT_RO_LDS_WORDS + cit_ice_NSLOPE) <= 160 * 1024, "tables + interval quotients beyond the 160 KB of LDS");
@@ -22,6 +23,8 @@ static_assert(8 * (CIT_RO_LDS_WORDS + cit_ice_NSLOPE) <= 160 * 1024, "tables + i
 #define CIT_SLOPE_DESC cit_ice_slope_desc      // (precomputed x-direction quotients of the tables: rollout_variant.inc stages them, citation_leaves.h cit_lookup2d_at_s)
 #define CIT_SLOPE_TABLES cit_ice_NSLOPE_TABLES
 #define CIT_USE_HINTS cit_ice_NSEARCH
+#define CIT_DW_IN_MEMORY 1
+#define CIT_Y_IS_STATE 1      // (gen/citation_ice_lane.inc: `if (major) c->Y[i] = X[i]`, i < 12 -- the outputs of step() are the states in front of the integration)
 #include "citation_step_dev.h"
 #include "rollout_variant.inc"
 #undef CIT_NO_AXES
