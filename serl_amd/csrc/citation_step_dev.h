@@ -16,7 +16,11 @@
 static __device__ CIT_STEP_ATTR void CIT_STEP(CitCtx *gc, const double *cmd_in, double *out_arg)
 {
   CitCtx lc;
+#ifdef CIT_CMD_IN_MEMORY
+  double y[19], f[6][19], out[12];
+#else
   double y[19], f[6][19], cmd[10], out[12];
+#endif      // (y as a seventh row of f -- kept in the stack frame instead of 38 registers -- measured worse: 198 against 124 scratch loads per evaluation body)
   for (int i = 0; i < 19; ++i) { lc.X[i] = gc->X[i]; y[i] = lc.X[i]; }
 #ifdef CIT_DW_IN_MEMORY      // (the DAG evaluation reads the banks where it needs them and writes them in the major step: gen/citation_<v>_lane.inc)
   lc.dwm = gc->DW;
@@ -30,7 +34,11 @@ static __device__ CIT_STEP_ATTR void CIT_STEP(CitCtx *gc, const double *cmd_in, 
 #ifdef CIT_USE_HINTS
   for (int i = 0; i < (CIT_USE_HINTS + 5) / 6; ++i) lc.hint[i] = gc->hint[i];
 #endif
+#ifdef CIT_CMD_IN_MEMORY      // (the DAG evaluation reads the command words from the caller's array where it needs them)
+  const double *cmd = cmd_in;
+#else
   for (int i = 0; i < 10; ++i) cmd[i] = cmd_in[i];
+#endif
   lc.t = gc->t; lc.stop_time = gc->stop_time; lc.dt = gc->dt; lc.tick = gc->tick;
   lc.ro = gc->ro; lc.t3 = gc->t3; lc.err = gc->err; lc.bslot = gc->bslot;
   const double t0 = lc.t, h = lc.dt;
@@ -85,3 +93,4 @@ static __device__ CIT_STEP_ATTR void CIT_STEP(CitCtx *gc, const double *cmd_in, 
 #undef CIT_USE_HINTS
 #undef CIT_Y_IS_STATE
 #undef CIT_DW_IN_MEMORY
+#undef CIT_CMD_IN_MEMORY

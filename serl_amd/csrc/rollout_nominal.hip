@@ -13,7 +13,15 @@ namespace bdag {
 #define CIT_B_AT(i) (c->B[(i)])
 #define SERL_FLAVOUR_LDS 0
 #define CIT_NO_AXES 1
+// the banks live in the CALLER's stack frame: a private-segment pointer, so that the reads are scratch loads (vmcnt) and not flat loads, which also count on
+// the LDS counter the table reads wait on (65 536 episodes: 219.6 -> 225.9 M env-steps/s)
+#ifndef CIT_CTX_FLAT
+#define CIT_DWM_PTR __attribute__((address_space(5))) double *
+#define CIT_CMD_PTR const __attribute__((address_space(5))) double *
+#else
 #define CIT_DWM_PTR double *
+#define CIT_CMD_PTR const double *
+#endif
 #include "gen/citation_nominal_lane.inc"
 static_assert(cit_nominal_RO_HI_W - cit_nominal_RO_LO_W <= CIT_RO_LDS_WORDS, "LDS table window too small");
 static_assert(8 * (CIT_RO_LDS_WORDS + cit_nominal_NSLOPE) <= 160 * 1024, "tables + interval quotients beyond the 160 KB of LDS");
@@ -24,6 +32,9 @@ static_assert(8 * (CIT_RO_LDS_WORDS + cit_nominal_NSLOPE) <= 160 * 1024, "tables
 #define CIT_SLOPE_TABLES cit_nominal_NSLOPE_TABLES
 #define CIT_USE_HINTS cit_nominal_NSEARCH      // (the index searches verify the previous evaluation's interval first: CitCtx.hint travels with the state)
 #define CIT_DW_IN_MEMORY 1
+#ifdef CIT_WITH_CMD_IN_MEMORY      // (A/B builds around gen files made with CITW_LANE_CMDMEM=1: measured slower)
+#define CIT_CMD_IN_MEMORY 1
+#endif
 #define CIT_Y_IS_STATE 1      // (gen/citation_nominal_lane.inc: `if (major) c->Y[i] = X[i]`, i < 12 -- the outputs of step() are the states in front of the integration)
 #include "citation_step_dev.h"
 #include "rollout_variant.inc"
