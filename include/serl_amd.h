@@ -132,9 +132,9 @@ typedef struct serl_rollout_desc {
                                        CUs), two / four episodes per team up to 4 x CUs (hidden 32; other hidden sizes: two
                                        per team up to 2 x CUs, six team + two actor wavefronts), beyond that ONE launch of
                                        four-episode teams with a work queue (a lane group takes the next episode when its
-                                       own ends) -- and from 80 x CUs episodes on (hidden 32, nominal / ice code) the lane-per-episode kernels with 64 episodes per wavefront --
+                                       own ends) -- and from 80 x CUs episodes on (hidden 32) the lane-per-episode kernels with 64 episodes per wavefront --
                                        or one wavefront per episode; 1..64 = lane-per-episode kernels with that
-                                       many episodes per wavefront (nominal / ice code variants, attitude task only) */
+                                       many episodes per wavefront (every code variant, attitude task only) */
   int32_t concurrent_episodes;      /* episodes of OTHER serl_rollout calls expected to run at the same time on other
                                        streams (mixed-build sweeps: one call per dynamics build); the kernel and the
                                        wavefronts per workgroup are chosen for n_episodes + concurrent_episodes so that

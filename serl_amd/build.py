@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(CSRC, 'libserl_amd.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-UNITS = ['serl_capi.hip', 'serl_ga.hip', 'serl_metrics.hip', 'serl_distill.hip', 'rollout_nominal.hip', 'rollout_ice.hip', 'rollout_wave_nominal.hip', 'rollout_wave_ice.hip',
+UNITS = ['serl_capi.hip', 'serl_ga.hip', 'serl_metrics.hip', 'serl_distill.hip', 'rollout_nominal.hip', 'rollout_ice.hip', 'rollout_cg_timed.hip', 'rollout_gust.hip', 'rollout_test.hip', 'rollout_wave_nominal.hip', 'rollout_wave_ice.hip',
          'rollout_wave_cg_timed.hip', 'rollout_wave_gust.hip', 'rollout_wave_test.hip', 'rollout_team_nominal.hip',
          'rollout_team_ice.hip', 'rollout_team_cg_timed.hip', 'rollout_team_gust.hip', 'rollout_team_test.hip',
          'rollout_team2_nominal.hip', 'rollout_team2_ice.hip', 'rollout_team2_cg_timed.hip', 'rollout_team2_gust.hip', 'rollout_team2_test.hip',

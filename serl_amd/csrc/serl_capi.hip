@@ -14,10 +14,32 @@ static thread_local std::string g_err;
 int serl_fail(int code, const std::string &msg) { g_err = msg; return code; }
 static int fail(int code, const std::string &msg) { return serl_fail(code, msg); }
 
-void serl_launch_rollout_nominal(const RolloutArgs &a, int grid, hipStream_t stream);
-void serl_launch_rollout_ice(const RolloutArgs &a, int grid, hipStream_t stream);
-void serl_launch_dyn_nominal(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
-void serl_launch_dyn_ice(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
+#define SERL_LANE_DECL(v) \
+  void serl_launch_rollout_##v(const RolloutArgs &a, int grid, hipStream_t stream); \
+  void serl_launch_dyn_##v(const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream);
+SERL_LANE_DECL(nominal) SERL_LANE_DECL(ice) SERL_LANE_DECL(cg_timed) SERL_LANE_DECL(gust) SERL_LANE_DECL(test)
+#undef SERL_LANE_DECL
+// the lane-per-episode kernels (rollout_<variant>.hip: one episode per lane around the branch-free DAG evaluation), one unit per code variant
+static void serl_launch_rollout_lane(int code, const RolloutArgs &a, int grid, hipStream_t stream)
+{
+  switch (code) {
+    case SERL_DYN_ICE: serl_launch_rollout_ice(a, grid, stream); break;
+    case SERL_DYN_CG_TIMED: serl_launch_rollout_cg_timed(a, grid, stream); break;
+    case SERL_DYN_GUST: serl_launch_rollout_gust(a, grid, stream); break;
+    case SERL_DYN_TEST: serl_launch_rollout_test(a, grid, stream); break;
+    default: serl_launch_rollout_nominal(a, grid, stream); break;
+  }
+}
+static void serl_launch_dyn_lane(int code, const RolloutArgs &a, const double *cmds, double *states, int T, int grid, hipStream_t stream)
+{
+  switch (code) {
+    case SERL_DYN_ICE: serl_launch_dyn_ice(a, cmds, states, T, grid, stream); break;
+    case SERL_DYN_CG_TIMED: serl_launch_dyn_cg_timed(a, cmds, states, T, grid, stream); break;
+    case SERL_DYN_GUST: serl_launch_dyn_gust(a, cmds, states, T, grid, stream); break;
+    case SERL_DYN_TEST: serl_launch_dyn_test(a, cmds, states, T, grid, stream); break;
+    default: serl_launch_dyn_nominal(a, cmds, states, T, grid, stream); break;
+  }
+}
 #define SERL_DECL_WAVE(v)                                                                                     \
   void serl_launch_rollout_wave_##v(const RolloutArgs &a, int grid, hipStream_t stream);                          \
   void serl_launch_rollout_wavex_##v(const RolloutArgs &a, int grid, hipStream_t stream);                         \
@@ -207,9 +229,9 @@ static void serl_launch_dyn_team(int code, const RolloutArgs &a, const double *c
 }
 
 // The wave-cooperative kernels (one wavefront per episode, rollout_wave.inc) exist for every code variant; the
-// lane-per-episode kernels (rollout_variant.inc, lanes_per_wave > 0) only for nominal and ice.
+// lane-per-episode kernels (rollout_variant.inc, lanes_per_wave > 0) for every code variant since round 6.
 static bool serl_has_wave_kernel(int code) { return code >= SERL_DYN_NOMINAL && code <= SERL_DYN_TEST; }
-static bool serl_has_lane_kernel(int code) { return code == SERL_DYN_NOMINAL || code == SERL_DYN_ICE; }
+static bool serl_has_lane_kernel(int code) { return code >= SERL_DYN_NOMINAL && code <= SERL_DYN_TEST; }
 
 // Lane-per-episode kernels (rollout_device.h serl_actor_forward_lane32_t): the population [members][stride] regrouped to [ceil(P / 4)][mpad][4], so that parameter
 // group g of 64 consecutive members is ONE run of 1 KB.  Reads run along a member's row, writes are 16 B pieces (30 MB for 2 048 SERL50 actors: microseconds in front of a
@@ -667,7 +689,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     return SERL_OK;
   }
   if (!serl_has_lane_kernel(s.code))
-    return fail(SERL_E_UNSUPPORTED, "serl_rollout: lanes_per_wave > 0 (lane-per-episode kernels) exists only for the nominal and ice code variants");
+    return fail(SERL_E_UNSUPPORTED, "serl_rollout: lanes_per_wave > 0 (lane-per-episode kernels): unknown code variant");
   if (lanes <= 0) {
     // A wavefront takes the same time per env step whether it carries 1 or 64 episodes, and wavefronts that
     // share a CU slow each other down (measured: profiles/r01_microbench.md), so episodes are spread one
@@ -686,8 +708,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
     if (rc != SERL_OK) return rc;
   }
   if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
-  if (s.code == SERL_DYN_NOMINAL) serl_launch_rollout_nominal(a, grid, stream);
-  else serl_launch_rollout_ice(a, grid, stream);
+  serl_launch_rollout_lane(s.code, a, grid, stream);
   HIP_TRY(hipGetLastError());
   serl_note_launch(c, SERL_FAMILY_LANE, grid, lanes, false, 0, true, 1, s.code);
   if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
@@ -837,7 +858,7 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
     return SERL_OK;
   }
   if (!serl_has_lane_kernel(s.code))
-    return fail(SERL_E_UNSUPPORTED, "serl_dyn_open_loop: lanes_per_wave > 0 exists only for the nominal and ice code variants");
+    return fail(SERL_E_UNSUPPORTED, "serl_dyn_open_loop: lanes_per_wave > 0: unknown code variant");
   int lanes = lanes_per_wave <= 0 ? (n_episodes + 255) / 256 : lanes_per_wave;
   if (lanes > 64) lanes = 64;
   a.lanes = lanes;
@@ -846,8 +867,7 @@ int serl_dyn_open_loop(serl_ctx *c, int slot, int32_t n_episodes, int32_t T, con
   a.block = 64 * wpb;
   const int grid = (nwaves + wpb - 1) / wpb;
   HIP_TRY(hipEventRecord(c->ev0, stream));
-  if (s.code == SERL_DYN_NOMINAL) serl_launch_dyn_nominal(a, cmds, states, T, grid, stream);
-  else serl_launch_dyn_ice(a, cmds, states, T, grid, stream);
+  serl_launch_dyn_lane(s.code, a, cmds, states, T, grid, stream);
   HIP_TRY(hipGetLastError());
   serl_note_launch(c, SERL_FAMILY_LANE, grid, lanes, false, 0, false, 1, s.code);
   HIP_TRY(hipEventRecord(c->ev1, stream));

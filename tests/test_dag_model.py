@@ -62,12 +62,12 @@ def test_generated_team_sources_are_current(variant):
     assert text == have, 'serl_amd/csrc/gen/citation_%s_team.inc is stale: run python tools/dag/codegen_team.py' % variant
 
 
-@pytest.mark.parametrize('variant', ['nominal', 'ice'])
+@pytest.mark.parametrize('variant', ['nominal', 'ice', 'cg_timed', 'gust', 'test'])
 def test_generated_lane_sources_are_current(variant):
     import codegen_lane
     text = codegen_lane.LaneGen(variant).emit_lane()
     have = open(os.path.join(ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_lane.inc' % variant)).read()
-    assert text == have, 'serl_amd/csrc/gen/citation_%s_lane.inc is stale: run python tools/dag/codegen_lane.py nominal ice' % variant
+    assert text == have, 'serl_amd/csrc/gen/citation_%s_lane.inc is stale: run python tools/dag/codegen_lane.py nominal ice cg_timed gust test' % variant
 
 
 @pytest.mark.parametrize('variant', ['nominal', 'ice', 'cg_timed', 'gust', 'test'])
@@ -225,7 +225,7 @@ def test_interpolation_over_precomputed_quotients_equals_the_reference_order(tmp
     r = subprocess.run([exe], capture_output=True, text=True)
     bad, n = (int(x) for x in r.stdout.split())
     assert r.returncode == 0 and bad == 0 and n == 200000, r.stdout
-    for v in ('nominal', 'ice'):
+    for v in ('nominal', 'ice', 'cg_timed', 'gust', 'test'):
         text = open(os.path.join(ROOT, 'serl_amd', 'csrc', 'gen', 'citation_%s_lane.inc' % v)).read()
         words, tables = (int(x) for x in re.search(r'cit_%s_NSLOPE = (\d+), cit_%s_NSLOPE_TABLES = (\d+)' % (v, v), text).groups())
         rows = re.findall(r'^  \{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},$', text, re.M)
