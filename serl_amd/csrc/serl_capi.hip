@@ -256,6 +256,10 @@ static int serl_regroup_weights(serl_ctx *c, const serl_rollout_desc *d, Rollout
   const size_t bytes = (size_t)groups * mpad * 16;
   const int slot = c->wt_next;
   c->wt_next = (c->wt_next + 1) % SERL_WT_SLOTS;
+  // a launch on another stream may still read the copy this slot held (more than SERL_WT_SLOTS lane launches in flight): order this launch behind it
+  if (c->wt_done[slot]) HIP_TRY(hipStreamWaitEvent(stream, c->wt_done[slot], 0));
+  else HIP_TRY(hipEventCreateWithFlags(&c->wt_done[slot], hipEventDisableTiming));
+  c->wt_slot_of_launch = slot;
   if (c->wt_cap[slot] < bytes) {
     if (c->wt[slot]) HIP_TRY(hipFree(c->wt[slot]));      // (waits for the launches that read it)
     c->wt[slot] = nullptr; c->wt_cap[slot] = 0;
@@ -425,7 +429,7 @@ int serl_ctx_destroy(serl_ctx *c)
   (void)hipSetDevice(c->device);
   for (auto &s : c->slots) if (s.blob) (void)hipFree(s.blob);
   if (c->mail) (void)hipFree(c->mail);
-  for (int i = 0; i < SERL_WT_SLOTS; ++i) if (c->wt[i]) (void)hipFree(c->wt[i]);
+  for (int i = 0; i < SERL_WT_SLOTS; ++i) { if (c->wt[i]) (void)hipFree(c->wt[i]); if (c->wt_done[i]) (void)hipEventDestroy(c->wt_done[i]); }
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->prof) (void)hipFree(c->prof);
@@ -710,6 +714,7 @@ int serl_rollout(serl_ctx *c, const serl_rollout_desc *d, void *stream_)
   if (timed) HIP_TRY(hipEventRecord(c->ev0, stream));
   serl_launch_rollout_lane(s.code, a, grid, stream);
   HIP_TRY(hipGetLastError());
+  if (a.wt) HIP_TRY(hipEventRecord(c->wt_done[c->wt_slot_of_launch], stream));
   serl_note_launch(c, SERL_FAMILY_LANE, grid, lanes, false, 0, true, 1, s.code);
   if (timed) HIP_TRY(hipEventRecord(c->ev1, stream));
   c->timed = timed;

@@ -56,5 +56,7 @@ struct serl_ctx {
   void *wt[SERL_WT_SLOTS] = {};         // lane-per-episode kernels: regrouped weights [ceil(P / 4)][members up to 64][4] of the launches in flight (a ring; grown on demand)
   size_t wt_cap[SERL_WT_SLOTS] = {};
   int wt_next = 0;
+  hipEvent_t wt_done[SERL_WT_SLOTS] = {};      // recorded behind the launch that reads a copy: the next launch to take the slot waits for it on ITS stream (no host wait)
+  int wt_slot_of_launch = -1;
   int32_t last_info[8] = {};            // serl_last_rollout_info: what the most recent rollout call launched (family, workgroups, episodes per team, queue, actor wavefronts, streamed, launches, code)
 };
