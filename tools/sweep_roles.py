@@ -24,7 +24,7 @@ def to_map(roles_of_wave):
 
 
 if __name__ == '__main__':
-    shipped = [0, 6, 2, 3, 4, 5, 1, 7]
+    shipped = [1, 3, 5, 0, 2, 4, 6, 7]      # SERL_TEAM_ROLES of rollout_team_<v>.hip (the LDS-resident actor; SERL_TEAMS_ROLES, beside a streaming actor, is 0 6 2 3 4 5 1 7)
     seen = set()
     out = ['%08x' % to_map(shipped)]
     seen.add(frozenset([frozenset((shipped[w], shipped[w + 4])) for w in range(4)]))
