@@ -7,4 +7,4 @@ python tools/dag/codegen.py $V
 python tools/dag/codegen_team.py $V
 python tools/dag/codegen_team.py $V --lane-groups        # gen/citation_<v>_teamg.inc: the partition of the two / four-episodes-per-team kernels
 python tools/dag/codegen_team.py $V --waves=6 --suffix=6
-python tools/dag/codegen_lane.py nominal ice
+python tools/dag/codegen_lane.py $V
