@@ -24,6 +24,8 @@ ap.add_argument('--t-max', type=float, default=20.0)
 ap.add_argument('--members', type=int, default=2048)
 ap.add_argument('--modes', default='lane64,auto')
 ap.add_argument('--reps', type=int, default=2)
+ap.add_argument('--order', choices=['interleaved', 'member-major'], default='interleaved',
+                help='interleaved: member = episode mod members (64 different members per wavefront: the worst case for the per-lane actor); member-major: member = episode // (episodes / members), the order evaluate_pop produces (agent.py:234-256: all episodes of a member one after the other)')
 ap.add_argument('--profile', action='store_true', help='with SERL_PROFILE=1 in the environment: cycles per env step wavefront 0 of workgroup 0 spent in the actor / dynamics / env bookkeeping (lane-per-episode kernels)')
 a = ap.parse_args()
 eng = serl_amd.RolloutEngine(0)
@@ -37,7 +39,7 @@ except Exception:
     peak = None
 base = None
 for E in [int(x) for x in a.episodes.split(',')]:
-    moe = (np.arange(E) % a.members).astype(np.int32)
+    moe = ((np.arange(E) % a.members) if a.order == 'interleaved' else (np.arange(E) // max(E // a.members, 1)) % a.members).astype(np.int32)
     for mode in a.modes.split(','):
         kw = dict(lanes_per_wave=int(mode[4:])) if mode.startswith('lane') else dict(kernel=None if mode == 'auto' else mode)
         ms = []
@@ -61,7 +63,7 @@ for E in [int(x) for x in a.episodes.split(',')]:
             extra['cycles_per_env_step_wave0'] = dict(actor=int(buf[0] / st), dynamics=int(buf[1] / st), env=int(buf[2] / st), steps=int(buf[3]))
         chk = eng.rollout(w, spec, moe[:64], ref, t_max=a.t_max, kernel='team')
         same = bool(torch.equal(chk['fitness'], out['fitness'][:64]) and torch.equal(chk['length_steps'], out['length_steps'][:64]))
-        print(json.dumps(dict(extra, what='saturating configuration (SURVEY 8d)', episodes=E, steps_per_episode=T, members=a.members, mode=mode, family=info['family'],
+        print(json.dumps(dict(extra, what='saturating configuration (SURVEY 8d)', order=a.order, episodes=E, steps_per_episode=T, members=a.members, mode=mode, family=info['family'],
                               workgroups=info['workgroups'], episodes_per_team_or_wave=info['episodes_per_team'], work_queue=info['work_queue'],
                               kernel_ms=[round(v, 2) for v in ms], env_steps=steps, env_steps_per_s=rate,
                               us_per_env_step_and_wavefront_or_team=k_ms * 1e3 / T,
