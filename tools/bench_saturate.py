@@ -24,12 +24,13 @@ ap.add_argument('--t-max', type=float, default=20.0)
 ap.add_argument('--members', type=int, default=2048)
 ap.add_argument('--modes', default='lane64,auto')
 ap.add_argument('--reps', type=int, default=2)
+ap.add_argument('--activation', default='tanh', help="tanh (the shipped SERL50 actors) | relu | elu: what the per-lane actor's 96 hidden activations cost (the weights stay the tanh actors': the flights differ)")
 ap.add_argument('--order', choices=['interleaved', 'member-major'], default='interleaved',
                 help='interleaved: member = episode mod members (64 different members per wavefront: the worst case for the per-lane actor); member-major: member = episode // (episodes / members), the order evaluate_pop produces (agent.py:234-256: all episodes of a member one after the other)')
 ap.add_argument('--profile', action='store_true', help='with SERL_PROFILE=1 in the environment: cycles per env step wavefront 0 of workgroup 0 spent in the actor / dynamics / env bookkeeping (lane-per-episode kernels)')
 a = ap.parse_args()
 eng = serl_amd.RolloutEngine(0)
-spec = serl_amd.NetSpec(7, 3, 32, 3, 'tanh')
+spec = serl_amd.NetSpec(7, 3, 32, 3, a.activation)
 w = bench.make_population(a.members, 0, tag='serl50').to(eng.device)
 ref = refsignals.tabulate(*refsignals.base_reference(a.t_max), a.t_max)
 T = ref.shape[0]
